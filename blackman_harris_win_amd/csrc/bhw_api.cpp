@@ -1,0 +1,473 @@
+// bhw_api.cpp -- host side of the C ABI (include/bhw.h): parameter validation, resolution of a
+// (model, widths) tuple into kernel constants, strategy choice, per-device scratch, launches.
+//
+// Host mirror of the reference's own host code: cpp/cordic_sincos.cpp:12-36 derives the rescaled
+// ROM, gain and z scaling per call; hls/windows/win_function.cpp:74-96 does the same for the HLS
+// model; src/cordic_dds.vhd:97-131,159-166 at elaboration.  Here that derivation runs once per call
+// on the host and is handed to the kernels as a kernel-argument struct.  No per-sample arithmetic
+// happens on the host: every compute entry point fails with BHW_ERR_HIP when no device is usable.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "bhw_internal.h"
+#include "bhw_tables.inc"
+
+extern "C" void bhw_taylor_rom(uint32_t dat_width, uint32_t lut_size, int32_t *rom_sin_cos);
+extern "C" uint32_t bhw_taylor_pi_word(int e);
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+int fail_hip(int hip_code, const char *what)
+{
+    return fail(BHW_ERR_HIP, "%s: %s (hipError %d)", what, hipGetErrorString((hipError_t)hip_code), hip_code);
+}
+
+int terms_of(uint32_t win_type)
+{
+    switch (win_type) {
+    case BHW_WIN_HAMMING: case BHW_WIN_HANN: return 2;
+    case BHW_WIN_BH3: return 3;
+    case BHW_WIN_BH4: return 4;
+    case BHW_WIN_BH5: return 5;
+    case BHW_WIN_BH7: return 7;
+    default: return 0;
+    }
+}
+
+// Built-in float weights: hls/windows/win_function.cpp:173-174,191-192,206-208,253-256,306-310,341-347.
+const double kHamming[2] = {0.5434783, 1 - 0.5434783};
+const double kHann[2] = {0.5, 0.5};
+const double kBh3[3] = {0.21, 0.25, 0.04};
+const double kBh4[4] = {0.35875, 0.48829, 0.14128, 0.01168};
+const double kBh5[5] = {0.3232153788877343, 0.4714921439576260, 0.1755341299601972, 0.0284969901061499,
+                        0.0012613570882927};
+const double kBh7[7] = {0.271220360585039, 0.433444612327442, 0.218004122892930, 0.065785343295606,
+                        0.010761867305342, 0.000770012710581, 0.000013680883060};
+
+int validate(const bhw_params *p)
+{
+    if (!p) return fail(BHW_ERR_BADARG, "params is NULL");
+    if (p->struct_size != sizeof(bhw_params))
+        return fail(BHW_ERR_BADARG, "struct_size %u != %zu", p->struct_size, sizeof(bhw_params));
+    if (p->model > BHW_MODEL_VHDL) return fail(BHW_ERR_BADARG, "model %u", p->model);
+    if (p->combine > BHW_COMBINE_VHDL) return fail(BHW_ERR_BADARG, "combine %u", p->combine);
+    if (p->sin_type > BHW_SIN_TAYLOR) return fail(BHW_ERR_BADARG, "sin_type %u", p->sin_type);
+    const uint32_t K = p->n_terms;
+    if (!(K == 2 || K == 3 || K == 4 || K == 5 || K == 7)) return fail(BHW_ERR_BADARG, "n_terms %u (2,3,4,5,7)", K);
+    const uint32_t PW = p->phi_width, W = p->dat_width;
+    if (PW < 4 || PW > 30) return fail(BHW_ERR_BADARG, "phi_width %u outside 4..30", PW);
+    if (W < 8 || W > 32) return fail(BHW_ERR_BADARG, "dat_width %u outside 8..32", W);
+    if (p->sin_type == BHW_SIN_TAYLOR) {
+        // win_selector wires the Taylor source only to HAMMING and BH3TERM: src/win_selector.vhd:93-135
+        if (K > 3) return fail(BHW_ERR_UNSUPPORTED, "Taylor source exists only for 2- and 3-term windows");
+        const uint32_t L = p->lut_size;
+        if (L < 1 || L > 16) return fail(BHW_ERR_BADARG, "lut_size %u outside 1..16", L);
+        const uint32_t pw_min = (K == 3) ? PW - 1 : PW;  // bh_win_3term.vhd:221-226
+        for (uint32_t pw = pw_min; pw <= PW; ++pw) {
+            const int d = (int)pw - (int)L;
+            if (d > 2) {
+                if (d - 3 > 15) return fail(BHW_ERR_UNSUPPORTED, "Taylor STAGE %d > 15 (tay1_order cnt_exp is 16 bits)", d - 3);
+                if (W < 19 && 19 + L + W > 48) return fail(BHW_ERR_UNSUPPORTED, "Taylor narrow path: 19+L+W > 48 DSP bits");
+                if (W > 18 && 19 + L + W > 62) return fail(BHW_ERR_UNSUPPORTED, "Taylor wide path: 19+L+W > 62 product bits");
+            }
+        }
+        return BHW_OK;
+    }
+    if (p->model == BHW_MODEL_HLS && PW > W + 2)
+        return fail(BHW_ERR_UNSUPPORTED, "HLS model is ill-defined for phi_width > dat_width + 2 (init_t truncation)");
+    if (p->model == BHW_MODEL_VHDL && (p->precision < 1 || p->precision > 7))
+        return fail(BHW_ERR_BADARG, "precision %u outside 1..7", p->precision);
+    return BHW_OK;
+}
+
+// Resolve the CORDIC constants.
+void resolve_cordic(const bhw_params *p, BhwCordicCfg &c)
+{
+    memset(&c, 0, sizeof c);
+    const uint32_t PW = p->phi_width, W = p->dat_width;
+    c.phi_width = PW;
+    c.dat_width = W;
+    uint32_t n_lut = W - 1;
+    switch (p->model) {
+    case BHW_MODEL_HLS:  // hls/windows/win_function.cpp:77-96
+        for (uint32_t i = 0; i < n_lut; ++i) c.lut[i] = kAtanT4[i] >> (47 - W);
+        c.x0 = kGain46 >> (46 - W);
+        c.n_iter = W;
+        if (PW - 1 < W) { c.z_shr = 0; c.z_shl = W - PW + 2; } else { c.z_shr = PW - W; c.z_shl = 2; }
+        c.out_shr = 2;
+        c.ones_neg = 0;
+        c.wide = (W + 2 > 32);
+        break;
+    case BHW_MODEL_CPP:  // cpp/cordic_sincos.cpp:15-36
+        for (uint32_t i = 0; i < n_lut; ++i) c.lut[i] = kAtanT2[i] >> (47 - W);
+        c.x0 = kGain46 >> (46 - W);
+        c.n_iter = W;
+        if (PW - 1 < W) { c.z_shr = 0; c.z_shl = W - PW + 1; } else { c.z_shr = PW - W; c.z_shl = 1; }
+        c.out_shr = 2;
+        c.ones_neg = 1;
+        c.wide = (W + 2 > 32);
+        break;
+    default: {           // src/cordic_dds.vhd:97-131,159-166
+        const uint32_t P = p->precision, Wi = W + P;
+        for (uint32_t i = 0; i < n_lut; ++i) c.lut[i] = kAtanT4[i] >> (49 - Wi);
+        c.x0 = kGain47 >> (49 - Wi);
+        c.n_iter = W - 1;
+        if (PW >= W) { c.z_shr = PW - W; c.z_shl = P; } else { c.z_shr = 0; c.z_shl = W - PW + P; }
+        c.out_shr = P;
+        c.ones_neg = 0;
+        c.wide = (Wi > 32);
+        break;
+    }
+    }
+}
+
+void resolve_window(const bhw_params *p, BhwWinCfg &w)
+{
+    memset(&w, 0, sizeof w);
+    for (int k = 0; k < 7; ++k) w.aa[k] = p->aa[k];
+    w.n_terms = p->n_terms;
+    w.combine = p->combine;
+}
+
+// ---- per-device library-owned scratch ---------------------------------------------------------
+struct DeviceScratch {
+    void *buf = nullptr;
+    uint64_t bytes = 0;
+    // Taylor ROM cache keyed by (W, L)
+    std::map<std::pair<uint32_t, uint32_t>, int32_t *> roms;
+};
+std::mutex g_mu;
+std::map<int, DeviceScratch> g_scratch;
+
+int ensure_scratch(int device, uint64_t bytes, void **out)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceScratch &s = g_scratch[device];
+    if (s.bytes < bytes) {
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+        if (s.buf) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(s.buf);
+            s.buf = nullptr;
+            s.bytes = 0;
+        }
+        e = hipMalloc(&s.buf, bytes);
+        if (e != hipSuccess) return fail_hip(e, "hipMalloc(scratch)");
+        s.bytes = bytes;
+    }
+    *out = s.buf;
+    return BHW_OK;
+}
+
+int get_taylor_rom(int device, void *stream, uint32_t W, uint32_t L, const int32_t **rom)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceScratch &s = g_scratch[device];
+    auto key = std::make_pair(W, L);
+    auto it = s.roms.find(key);
+    if (it != s.roms.end()) { *rom = it->second; return BHW_OK; }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+    std::vector<int32_t> host(2u << L);
+    bhw_taylor_rom(W, L, host.data());
+    int32_t *d = nullptr;
+    e = hipMalloc((void **)&d, host.size() * sizeof(int32_t));
+    if (e != hipSuccess) return fail_hip(e, "hipMalloc(rom)");
+    e = hipMemcpy(d, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return fail_hip(e, "hipMemcpy(rom)"); }
+    (void)stream;
+    s.roms[key] = d;
+    *rom = d;
+    return BHW_OK;
+}
+
+int resolve_taylor(const bhw_params *p, int device, void *stream, BhwTaylorCfg &t)
+{
+    memset(&t, 0, sizeof t);
+    t.phi_width = p->phi_width;
+    t.dat_width = p->dat_width;
+    t.lut_size = p->lut_size;
+    const int d = (int)p->phi_width - (int)p->lut_size;
+    t.mode = d < 2 ? 0u : d == 2 ? 1u : 2u;
+    t.xshift = 19 + p->lut_size;
+    t.pi_word = d > 2 ? bhw_taylor_pi_word(17 - (d - 3)) : 0;          // tay1_order.vhd:133, STAGE = PW-L-3
+    t.pad[0] = (d - 1) > 2 ? bhw_taylor_pi_word(17 - (d - 4)) : 0;      // 2nd generator at PHASE_WIDTH-1
+    return get_taylor_rom(device, stream, p->dat_width, p->lut_size, &t.rom);
+}
+
+bool device_ok(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return false;
+    return device >= 0 && device < n;
+}
+
+uint64_t table_entries(const BhwCordicCfg &c) { return 1ull << (c.phi_width - 2 - c.z_shr); }
+
+// AUTO: build the shared table when it replaces clearly more CORDIC chains than it costs.
+uint32_t pick_algo(const bhw_params *p, const BhwCordicCfg &c, uint64_t count, uint32_t requested)
+{
+    if (p->sin_type == BHW_SIN_TAYLOR) return BHW_ALGO_DIRECT;
+    if (requested == BHW_ALGO_DIRECT || requested == BHW_ALGO_TABLE) return requested;
+    const uint64_t chains_direct = count * (p->n_terms - 1);
+    return chains_direct >= 2 * table_entries(c) ? BHW_ALGO_TABLE : BHW_ALGO_DIRECT;
+}
+
+int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, uint64_t count, int32_t *d_out,
+                  const bhw_exec *ex)
+{
+    int rc = validate(p);
+    if (rc) return rc;
+    if (count && !d_out) return fail(BHW_ERR_BADARG, "d_out is NULL");
+    if (ex && ex->struct_size != sizeof(bhw_exec)) return fail(BHW_ERR_BADARG, "bhw_exec.struct_size");
+    if (!count) return BHW_OK;
+    if (!device_ok(device)) return fail(BHW_ERR_HIP, "no usable HIP device %d (this library has no CPU path)", device);
+    BhwLaunch l{device, stream};
+    BhwWinCfg w;
+    resolve_window(p, w);
+    if (p->sin_type == BHW_SIN_TAYLOR) {
+        BhwTaylorCfg t;
+        rc = resolve_taylor(p, device, stream, t);
+        if (rc) return rc;
+        int e = bhwk_taylor_window(l, t, w, n0, count, d_out);
+        return e ? fail_hip(e, "taylor window launch") : BHW_OK;
+    }
+    BhwCordicCfg c;
+    resolve_cordic(p, c);
+    const uint32_t algo = pick_algo(p, c, count, ex ? ex->algo : BHW_ALGO_AUTO);
+    if (algo == BHW_ALGO_DIRECT) {
+        int e = bhwk_direct(l, c, w, n0, count, d_out);
+        return e ? fail_hip(e, "direct launch") : BHW_OK;
+    }
+    const uint64_t need = table_entries(c) * 8ull;
+    void *ws = nullptr;
+    if (ex && ex->workspace) {
+        if (ex->workspace_bytes < need)
+            return fail(BHW_ERR_WORKSPACE, "workspace %llu < %llu bytes", (unsigned long long)ex->workspace_bytes,
+                        (unsigned long long)need);
+        ws = ex->workspace;
+    } else {
+        rc = ensure_scratch(device, need, &ws);
+        if (rc) return rc;
+    }
+    int e = bhwk_table_build(l, c, (int32_t *)ws);
+    if (e) return fail_hip(e, "table build launch");
+    e = bhwk_table_combine(l, c, w, (const int32_t *)ws, n0, count, d_out);
+    return e ? fail_hip(e, "table combine launch") : BHW_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t bhw_abi_version(void) { return BHW_ABI_VERSION; }
+
+const char *bhw_strerror(int code)
+{
+    switch (code) {
+    case BHW_OK: return "ok";
+    case BHW_ERR_BADARG: return "bad argument";
+    case BHW_ERR_UNSUPPORTED: return "unsupported parameter combination";
+    case BHW_ERR_HIP: return "HIP runtime error or no device";
+    case BHW_ERR_WORKSPACE: return "workspace too small";
+    default: return "unknown error";
+    }
+}
+
+const char *bhw_last_error(void) { return g_last_error.c_str(); }
+
+int bhw_coeffs_from_float(uint32_t win_type, uint32_t dat_width, const double *a, int32_t aa[7])
+{
+    const int K = terms_of(win_type);
+    if (!K) return fail(BHW_ERR_BADARG, "win_type %u", win_type);
+    if (dat_width < 8 || dat_width > 32) return fail(BHW_ERR_BADARG, "dat_width %u outside 8..32", dat_width);
+    if (!aa) return fail(BHW_ERR_BADARG, "aa is NULL");
+    if (!a) {
+        switch (win_type) {
+        case BHW_WIN_HAMMING: a = kHamming; break;
+        case BHW_WIN_HANN: a = kHann; break;
+        case BHW_WIN_BH3: a = kBh3; break;
+        case BHW_WIN_BH4: a = kBh4; break;
+        case BHW_WIN_BH5: a = kBh5; break;
+        default: a = kBh7; break;
+        }
+    }
+    // s = 1: win_function.cpp:176-177,210-212,258-261; s = 2: :312-316,349-355.  C round(): half away from zero.
+    const unsigned s = (K >= 5) ? 2 : 1;
+    const double scale = std::pow(2.0, (double)(dat_width - s)) - 1.0;
+    for (int k = 0; k < 7; ++k) aa[k] = 0;
+    for (int k = 0; k < K; ++k) aa[k] = (int32_t)(int64_t)std::round(a[k] * scale);
+    return BHW_OK;
+}
+
+int bhw_params_init(bhw_params *p, uint32_t win_type, uint32_t phi_width, uint32_t dat_width)
+{
+    if (!p) return fail(BHW_ERR_BADARG, "params is NULL");
+    memset(p, 0, sizeof *p);
+    p->struct_size = sizeof *p;
+    p->model = BHW_MODEL_HLS;
+    p->combine = BHW_COMBINE_HLS;
+    p->sin_type = BHW_SIN_CORDIC;
+    p->win_type = win_type;
+    p->n_terms = (uint32_t)terms_of(win_type);
+    p->phi_width = phi_width;
+    p->dat_width = dat_width;
+    p->precision = 1;
+    p->lut_size = 9;
+    if (!p->n_terms) return fail(BHW_ERR_BADARG, "win_type %u", win_type);
+    int rc = bhw_coeffs_from_float(win_type, dat_width, nullptr, p->aa);
+    if (rc) return rc;
+    return validate(p);
+}
+
+int bhw_params_validate(const bhw_params *p) { return validate(p); }
+
+int bhw_constant_tables(uint32_t which, int64_t table[48], int64_t gains[2])
+{
+    if (which > 1) return fail(BHW_ERR_BADARG, "which %u", which);
+    if (table) memcpy(table, which ? kAtanT4 : kAtanT2, 48 * sizeof(int64_t));
+    if (gains) { gains[0] = kGain46; gains[1] = kGain47; }
+    return BHW_OK;
+}
+
+int bhw_generate_device(const bhw_params *p, int device, void *hip_stream, uint64_t n0, uint64_t count, int32_t *d_out)
+{
+    return generate_impl(p, device, hip_stream, n0, count, d_out, nullptr);
+}
+
+int bhw_generate_device_ex(const bhw_params *p, int device, void *hip_stream, uint64_t n0, uint64_t count,
+                           int32_t *d_out, const bhw_exec *ex)
+{
+    return generate_impl(p, device, hip_stream, n0, count, d_out, ex);
+}
+
+uint64_t bhw_workspace_bytes(const bhw_params *p, uint64_t n0, uint64_t count, uint32_t algo)
+{
+    (void)n0;
+    if (validate(p)) return 0;
+    if (p->sin_type == BHW_SIN_TAYLOR) return 0;
+    BhwCordicCfg c;
+    resolve_cordic(p, c);
+    return pick_algo(p, c, count, algo) == BHW_ALGO_TABLE ? table_entries(c) * 8ull : 0;
+}
+
+int bhw_generate_batched_device(const bhw_params *p, int device, void *hip_stream, uint32_t frames, int32_t *d_out)
+{
+    int rc = validate(p);
+    if (rc) return rc;
+    if (!frames) return BHW_OK;
+    if (!d_out) return fail(BHW_ERR_BADARG, "d_out is NULL");
+    const uint64_t N = 1ull << p->phi_width;
+    // frame 0 is generated in place, then replicated into frames 1..frames-1
+    rc = generate_impl(p, device, hip_stream, 0, N, d_out, nullptr);
+    if (rc || frames == 1) return rc;
+    BhwLaunch l{device, hip_stream};
+    int e = bhwk_replicate(l, d_out, N, frames - 1, d_out + N);
+    return e ? fail_hip(e, "replicate launch") : BHW_OK;
+}
+
+int bhw_sincos_device(const bhw_params *p, int device, void *hip_stream, uint64_t theta0, uint64_t count,
+                      int32_t *d_sin, int32_t *d_cos)
+{
+    int rc = validate(p);
+    if (rc) return rc;
+    if (!count) return BHW_OK;
+    if (!d_sin && !d_cos) return fail(BHW_ERR_BADARG, "both outputs NULL");
+    if (!device_ok(device)) return fail(BHW_ERR_HIP, "no usable HIP device %d (this library has no CPU path)", device);
+    BhwLaunch l{device, hip_stream};
+    if (p->sin_type == BHW_SIN_TAYLOR) {
+        BhwTaylorCfg t;
+        rc = resolve_taylor(p, device, hip_stream, t);
+        if (rc) return rc;
+        int e = bhwk_taylor_sincos(l, t, theta0, count, d_sin, d_cos);
+        return e ? fail_hip(e, "taylor sincos launch") : BHW_OK;
+    }
+    BhwCordicCfg c;
+    resolve_cordic(p, c);
+    int e = bhwk_sincos(l, c, theta0, count, d_sin, d_cos);
+    return e ? fail_hip(e, "sincos launch") : BHW_OK;
+}
+
+int bhw_generate_to_host(const bhw_params *p, int device, uint64_t n0, uint64_t count, int32_t *h_out)
+{
+    int rc = validate(p);
+    if (rc) return rc;
+    if (!count) return BHW_OK;
+    if (!h_out) return fail(BHW_ERR_BADARG, "h_out is NULL");
+    if (!device_ok(device)) return fail(BHW_ERR_HIP, "no usable HIP device %d (this library has no CPU path)", device);
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+    int32_t *d = nullptr;
+    e = hipMalloc((void **)&d, count * sizeof(int32_t));
+    if (e != hipSuccess) return fail_hip(e, "hipMalloc(out)");
+    rc = generate_impl(p, device, nullptr, n0, count, d, nullptr);
+    if (!rc) {
+        e = hipMemcpy(h_out, d, count * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail_hip(e, "hipMemcpy(D2H)");
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
+int bhw_sincos_to_host(const bhw_params *p, int device, uint64_t theta0, uint64_t count, int32_t *h_sin, int32_t *h_cos)
+{
+    int rc = validate(p);
+    if (rc) return rc;
+    if (!count) return BHW_OK;
+    if (!h_sin && !h_cos) return fail(BHW_ERR_BADARG, "both outputs NULL");
+    if (!device_ok(device)) return fail(BHW_ERR_HIP, "no usable HIP device %d (this library has no CPU path)", device);
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+    int32_t *d = nullptr;
+    e = hipMalloc((void **)&d, 2 * count * sizeof(int32_t));
+    if (e != hipSuccess) return fail_hip(e, "hipMalloc(out)");
+    rc = bhw_sincos_device(p, device, nullptr, theta0, count, d, d + count);
+    if (!rc && h_sin) {
+        e = hipMemcpy(h_sin, d, count * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail_hip(e, "hipMemcpy(D2H)");
+    }
+    if (!rc && h_cos) {
+        e = hipMemcpy(h_cos, d + count, count * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail_hip(e, "hipMemcpy(D2H)");
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
+int bhw_release_device(int device)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_scratch.find(device);
+    if (it == g_scratch.end()) return BHW_OK;
+    if (hipSetDevice(device) == hipSuccess) {
+        (void)hipDeviceSynchronize();
+        if (it->second.buf) (void)hipFree(it->second.buf);
+        for (auto &kv : it->second.roms) (void)hipFree(kv.second);
+    }
+    g_scratch.erase(it);
+    return BHW_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,60 @@
+// bhw_internal.h -- structures shared by the host-side ABI (bhw_api.cpp) and the HIP kernels.
+#pragma once
+#include <stdint.h>
+#include "../../include/bhw.h"
+
+// One CORDIC bit-model resolved to plain numbers for a (model, PW, W, PRECISION) tuple.
+//   model HLS : hls/windows/win_function.cpp:74-154   
+//   model CPP : cpp/cordic_sincos.cpp:12-90           
+//   model VHDL: src/cordic_dds.vhd:97-249             
+// All three run   x' = x -/+ (y >> k), y' = y +/- (x >> k), z' = z -/+ lut[k]   and differ only in
+// the constants below.
+struct BhwCordicCfg {
+    int64_t  lut[32];     // rescaled arctangent ROM; entries >= n_lut are 0
+    int64_t  x0;          // gain-compensated start value
+    uint32_t phi_width;   // PW
+    uint32_t dat_width;   // W
+    uint32_t n_iter;      // W (HLS, CPP) or W-1 (VHDL)
+    uint32_t z_shr;       // z0 = (t >> z_shr) << z_shl,  t = theta mod 2^(PW-2)
+    uint32_t z_shl;
+    uint32_t out_shr;     // 2 (HLS, CPP) or PRECISION (VHDL)
+    uint32_t ones_neg;    // 1: quadrant map negates with ~v (CPP); 0: -v
+    uint32_t wide;        // 1: state needs more than 32 bits
+};
+
+// Cosine-sum stage.
+struct BhwWinCfg {
+    int32_t  aa[8];
+    uint32_t n_terms;
+    uint32_t combine;     // BHW_COMBINE_*
+    uint32_t pad[2];
+};
+
+// Taylor feeder (src/taylor_sincos.vhd + src/tay1_order.vhd).
+struct BhwTaylorCfg {
+    const int32_t *rom;   // device pointer: 2^lut_size (sin, cos) pairs, interleaved
+    uint32_t phi_width, dat_width, lut_size;
+    uint32_t mode;        // 0: PW-L < 2, 1: PW-L == 2, 2: PW-L > 2 (1st-order correction)
+    uint32_t pi_word;     // round(pi * 2^(17-STAGE))
+    uint32_t xshift;      // 19 + L
+    uint32_t pad[2];
+};
+
+struct BhwLaunch {
+    int   device;
+    void *stream;
+};
+
+// kernels (bhw_kernels.hip) -- each returns a hipError_t cast to int
+int bhwk_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w,
+                uint64_t n0, uint64_t count, int32_t *d_out);
+int bhwk_sincos(const BhwLaunch &l, const BhwCordicCfg &c, uint64_t theta0, uint64_t count,
+                int32_t *d_sin, int32_t *d_cos);
+int bhwk_replicate(const BhwLaunch &l, const int32_t *d_frame, uint64_t frame_len, uint32_t frames, int32_t *d_out);
+int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table /* (c,s) pairs, 2^(PW-2) */);
+int bhwk_table_combine(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table,
+                       uint64_t n0, uint64_t count, int32_t *d_out);
+int bhwk_taylor_window(const BhwLaunch &l, const BhwTaylorCfg &t, const BhwWinCfg &w,
+                       uint64_t n0, uint64_t count, int32_t *d_out);
+int bhwk_taylor_sincos(const BhwLaunch &l, const BhwTaylorCfg &t, uint64_t theta0, uint64_t count,
+                       int32_t *d_sin, int32_t *d_cos);

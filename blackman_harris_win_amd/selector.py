@@ -1,0 +1,143 @@
+"""Host-side mirror of the reference's operator interface, on top of the C ABI.
+
+torch is plumbing here: it owns the output tensor, the current stream and (in bench.py) the
+process group.  The arithmetic is in libbhw.so's HIP kernels.
+"""
+import ctypes
+
+from . import binding as B
+
+_WIN_TYPES = {
+    # WIN_TYPE generic strings of win_selector (src/win_selector.vhd:64,93,115,137,157,178) plus the
+    # HLS names (hls/windows/window_test.cpp:59-74)
+    "HAMMING": B.WIN_HAMMING, "HANN": B.WIN_HANN,
+    "BH3TERM": B.WIN_BH3, "BH4TERM": B.WIN_BH4, "BH5TERM": B.WIN_BH5, "BH7TERM": B.WIN_BH7,
+    "Hamming": B.WIN_HAMMING, "Hann": B.WIN_HANN, "Blackman-Harris-3": B.WIN_BH3,
+    "Blackman-Harris-4": B.WIN_BH4, "Blackman-Harris-5": B.WIN_BH5, "Blackman-Harris-7": B.WIN_BH7,
+}
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("no HIP device visible: the window generator runs only on the GPU (no CPU fallback)")
+    return torch
+
+
+def _stream_ptr(torch, device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _dev_index(torch, device):
+    d = torch.device("cuda" if device is None else device)
+    return torch.cuda.current_device() if d.index is None else d.index
+
+
+def shard_range(total, rank, world_size):
+    """Contiguous index shard [n0, n0+count) of `total` coefficients for `rank` (no collective)."""
+    base, rem = divmod(total, world_size)
+    n0 = rank * base + min(rank, rem)
+    return n0, base + (1 if rank < rem else 0)
+
+
+def generate(params, n0, count, *, device=None, out=None, algo=B.ALGO_AUTO, workspace=None):
+    """count coefficients starting at stream index n0 as an int32 CUDA tensor (bhw_generate_device)."""
+    torch = _torch()
+    dev = _dev_index(torch, device)
+    if out is None:
+        out = torch.empty(int(count), dtype=torch.int32, device=f"cuda:{dev}")
+    else:
+        if out.dtype != torch.int32 or not out.is_cuda or not out.is_contiguous() or out.numel() < count:
+            raise ValueError("out must be a contiguous int32 CUDA tensor with at least `count` elements")
+        dev = out.device.index
+    ex = B.BhwExec()
+    ex.struct_size = ctypes.sizeof(B.BhwExec)
+    ex.algo = algo
+    if workspace is not None:
+        ex.workspace = workspace.data_ptr()
+        ex.workspace_bytes = workspace.numel() * workspace.element_size()
+    with torch.cuda.device(dev):
+        B.check(B.lib().bhw_generate_device_ex(ctypes.byref(params), dev, _stream_ptr(torch, dev), int(n0), int(count),
+                                                ctypes.c_void_p(out.data_ptr()), ctypes.byref(ex)))
+    return out
+
+
+def generate_batched(params, frames, *, device=None, out=None):
+    """frames x 2^phi_width coefficients: one period computed, then replicated (bhw_generate_batched_device)."""
+    torch = _torch()
+    dev = _dev_index(torch, device)
+    n = 1 << params.phi_width
+    if out is None:
+        out = torch.empty((int(frames), n), dtype=torch.int32, device=f"cuda:{dev}")
+    dev = out.device.index
+    with torch.cuda.device(dev):
+        B.check(B.lib().bhw_generate_batched_device(ctypes.byref(params), dev, _stream_ptr(torch, dev), int(frames),
+                                                     ctypes.c_void_p(out.data_ptr())))
+    return out
+
+
+def cordic(params, theta0, count, *, device=None):
+    """(sin, cos) int32 CUDA tensors for phases theta0..theta0+count-1 (bhw_sincos_device)."""
+    torch = _torch()
+    dev = _dev_index(torch, device)
+    s = torch.empty(int(count), dtype=torch.int32, device=f"cuda:{dev}")
+    c = torch.empty(int(count), dtype=torch.int32, device=f"cuda:{dev}")
+    with torch.cuda.device(dev):
+        B.check(B.lib().bhw_sincos_device(ctypes.byref(params), dev, _stream_ptr(torch, dev), int(theta0), int(count),
+                                           ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(c.data_ptr())))
+    return s, c
+
+
+def win_function(win_type, i0, count, *, nphase, nwidth, device=None, **kw):
+    """HLS top function swept over i (hls/windows/win_function.h:65-69): unknown win_type -> zeros
+    (win_empty, hls/windows/win_function.cpp:159-165,417-419)."""
+    torch = _torch()
+    if win_type not in (1, 2, 3, 4, 5, 7):
+        return torch.zeros(int(count), dtype=torch.int32, device="cuda" if device is None else device)
+    p = B.make_params(win_type, nphase, nwidth, model=B.MODEL_HLS, combine=B.COMBINE_HLS, **kw)
+    return generate(p, i0, count, device=device)
+
+
+class WinSelector:
+    """entity win_selector (src/win_selector.vhd:60-87).
+
+    Generics become constructor arguments with the reference's names; the AA0..AA6 ports are the
+    `aa` list (integer, caller-scaled; None = the HLS model's built-in constants).  `model`/`combine`
+    choose which of the reference's bit-models to reproduce (default: the HLS C++ model).
+    """
+
+    def __init__(self, PHI_WIDTH=10, DAT_WIDTH=16, WIN_TYPE="HAMMING", SIN_TYPE="CORDIC", LUT_SIZE=9,
+                 XSERIES="ULTRA", aa=None, model=B.MODEL_HLS, combine=B.COMBINE_HLS, precision=1, device=None):
+        if WIN_TYPE not in _WIN_TYPES:
+            raise ValueError(f"WIN_TYPE {WIN_TYPE!r}: expected one of {sorted(_WIN_TYPES)}")
+        if SIN_TYPE not in ("CORDIC", "TAYLOR"):
+            raise ValueError("SIN_TYPE must be 'CORDIC' or 'TAYLOR'")
+        if XSERIES not in ("7SERIES", "ULTRA"):  # selects DSP48 port widths only (tay1_order.vhd:538-578)
+            raise ValueError("XSERIES must be '7SERIES' or 'ULTRA'")
+        self.device = device
+        self.params = B.make_params(
+            _WIN_TYPES[WIN_TYPE], PHI_WIDTH, DAT_WIDTH, model=model, combine=combine,
+            sin_type=B.SIN_TAYLOR if SIN_TYPE == "TAYLOR" else B.SIN_CORDIC,
+            precision=precision, lut_size=LUT_SIZE, aa=aa)
+        self._phase = 0  # the PHI_WIDTH-bit counter (RESET clears it: bh_win_7term.vhd:179-186)
+
+    @property
+    def length(self):
+        return 1 << self.params.phi_width
+
+    def reset(self):
+        self._phase = 0
+
+    def enable(self, count, out=None, algo=B.ALGO_AUTO):
+        """ENABLE high for `count` clocks: the next `count` values of DT_WIN; the counter advances and wraps."""
+        w = generate(self.params, self._phase, count, device=self.device, out=out, algo=algo)
+        self._phase = (self._phase + int(count)) % self.length
+        return w
+
+    def window(self, out=None, algo=B.ALGO_AUTO):
+        """One full period from phase 0."""
+        return generate(self.params, 0, self.length, device=self.device, out=out, algo=algo)
+
+    def shard(self, rank, world_size, out=None, algo=B.ALGO_AUTO):
+        n0, count = shard_range(self.length, rank, world_size)
+        return generate(self.params, n0, count, device=self.device, out=out, algo=algo)

@@ -1,0 +1,140 @@
+/*
+ * bhw.h -- C ABI of the MI355X fixed-point window-coefficient generator.
+ *
+ * Drop-in boundary for the reference's coefficient source.  The reference
+ * (hukenovs/blackman_harris_win) has no FFI layer; what a consumer binds is
+ *   - the `win_selector` entity, src/win_selector.vhd:60-87
+ *       generics PHI_WIDTH, DAT_WIDTH, WIN_TYPE, SIN_TYPE, LUT_SIZE, XSERIES
+ *       ports    AA0..AA6 (integer weights), ENABLE, DT_WIN, DT_VLD
+ *   - the HLS top   void win_function(char win_type, phi_t i, win_t *out)
+ *                                             hls/windows/win_function.h:65-69
+ *   - the CORDIC    void cordic(phi_t, win_t *cos, win_t *sin)
+ *                                             hls/windows/win_function.cpp:47-51
+ *                   void cordic(int theta, long long *lut, int *s, int *c)
+ *                                             cpp/cordic_sincos.cpp:10
+ * Each entry point below names the reference interface it replaces.
+ *
+ * Plain C types only: pointers, sizes, PODs.  No exceptions cross the ABI.
+ * All compute runs in hand-written HIP kernels on the selected device; there is
+ * no CPU fallback -- without a usable HIP device every compute entry point
+ * returns BHW_ERR_HIP.
+ */
+#ifndef BHW_H
+#define BHW_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BHW_ABI_VERSION 1u
+
+/* CORDIC bit-model (the reference holds three that are not bit-identical). */
+enum {
+    BHW_MODEL_HLS  = 0,  /* hls/windows/win_function.cpp:47-156 (= hls/cordic/cordic.cpp)   */
+    BHW_MODEL_CPP  = 1,  /* cpp/cordic_sincos.cpp:10-92                                      */
+    BHW_MODEL_VHDL = 2   /* src/cordic_dds.vhd:94-249                                        */
+};
+/* Cosine-sum rule. */
+enum {
+    BHW_COMBINE_HLS  = 0, /* truncating shift, no rounding: hls/windows/win_function.cpp:168-377 */
+    BHW_COMBINE_VHDL = 1  /* per-product round + final round: src/bh_win_7term.vhd:353-438 etc.  */
+};
+/* SIN_TYPE generic of win_selector (src/win_selector.vhd:66). */
+enum { BHW_SIN_CORDIC = 0, BHW_SIN_TAYLOR = 1 };
+/* win_type codes of win_function() (hls/windows/win_function.cpp:391-420). */
+enum { BHW_WIN_HAMMING = 1, BHW_WIN_HANN = 2, BHW_WIN_BH3 = 3, BHW_WIN_BH4 = 4, BHW_WIN_BH5 = 5, BHW_WIN_BH7 = 7 };
+/* Execution strategy (results are bit-identical across strategies). */
+enum {
+    BHW_ALGO_AUTO   = 0,
+    BHW_ALGO_DIRECT = 1, /* one lane per coefficient, K-1 CORDIC chains per lane              */
+    BHW_ALGO_TABLE  = 2  /* first-quadrant CORDIC table built once per call, then gather-combine */
+};
+
+enum {
+    BHW_OK              = 0,
+    BHW_ERR_BADARG      = -1,
+    BHW_ERR_UNSUPPORTED = -2,
+    BHW_ERR_HIP         = -3,
+    BHW_ERR_WORKSPACE   = -4
+};
+
+/* The win_selector parameter surface as one POD (src/win_selector.vhd:61-81). */
+typedef struct bhw_params {
+    uint32_t struct_size;  /* sizeof(bhw_params), for ABI evolution                       */
+    uint32_t model;        /* BHW_MODEL_*                                                 */
+    uint32_t combine;      /* BHW_COMBINE_*                                               */
+    uint32_t sin_type;     /* BHW_SIN_*                      SIN_TYPE                     */
+    uint32_t win_type;     /* BHW_WIN_* (informational; n_terms + aa define the window)   */
+    uint32_t n_terms;      /* 2,3,4,5,7                      WIN_TYPE                     */
+    uint32_t phi_width;    /* 4..26, N = 2^phi_width         PHI_WIDTH                    */
+    uint32_t dat_width;    /* 8..32                          DAT_WIDTH                    */
+    uint32_t precision;    /* model VHDL only, 1..7          cordic_dds PRECISION         */
+    uint32_t lut_size;     /* Taylor only                    LUT_SIZE                     */
+    int32_t  aa[7];        /* AA0..AA6, caller-scaled integer weights                     */
+} bhw_params;
+
+/* Optional execution controls for the *_ex entry points. */
+typedef struct bhw_exec {
+    uint32_t struct_size;     /* sizeof(bhw_exec)                                          */
+    uint32_t algo;            /* BHW_ALGO_*                                                */
+    void    *workspace;       /* device scratch (NULL: library-owned per-device scratch)   */
+    uint64_t workspace_bytes;
+} bhw_exec;
+
+uint32_t    bhw_abi_version(void);
+const char *bhw_strerror(int code);
+const char *bhw_last_error(void); /* thread-local detail of the last failure */
+
+/* Defaults: model HLS, combine HLS, CORDIC source, precision 1, lut_size 9, built-in a_k
+ * (hls/windows/win_function.cpp:173-355 constants and scaling). */
+int bhw_params_init(bhw_params *p, uint32_t win_type, uint32_t phi_width, uint32_t dat_width);
+int bhw_params_validate(const bhw_params *p);
+
+/* a_k = round(coe_k * (2^(W-s)-1)), s = 1 (2/3/4-term) or 2 (5/7-term): the HLS derivation
+ * (hls/windows/win_function.cpp:176-177,210-212,258-261,312-316,349-355).  a == NULL selects
+ * the built-in constants of `win_type`.  Host arithmetic only (doubles -> 7 integers). */
+int bhw_coeffs_from_float(uint32_t win_type, uint32_t dat_width, const double *a, int32_t aa[7]);
+
+/* The 48-entry arctangent ROMs and gains the kernels use (which: 0 = T2 of the cpp model,
+ * 1 = T4 of the HLS/VHDL models); gains[0] = G46, gains[1] = G47. */
+int bhw_constant_tables(uint32_t which, int64_t table[48], int64_t gains[2]);
+
+/* Replaces: ENABLE held high for `count` clocks on win_selector (src/win_selector.vhd:83-86)
+ * after the phase counter reached n0; equivalently `for i in n0..n0+count: win_function(sel, i, &w)`
+ * (hls/windows/window_test.cpp:93,193).  Writes count sign-extended int32 coefficients to d_out
+ * (device memory of `device`), asynchronously on `hip_stream` (hipStream_t; NULL = default
+ * stream).  n wraps modulo 2^phi_width like the hardware counter (src/bh_win_7term.vhd:92-97). */
+int bhw_generate_device(const bhw_params *p, int device, void *hip_stream,
+                        uint64_t n0, uint64_t count, int32_t *d_out);
+int bhw_generate_device_ex(const bhw_params *p, int device, void *hip_stream,
+                           uint64_t n0, uint64_t count, int32_t *d_out, const bhw_exec *ex);
+/* Device scratch the given call would need with `algo` (0 for the direct strategy). */
+uint64_t bhw_workspace_bytes(const bhw_params *p, uint64_t n0, uint64_t count, uint32_t algo);
+
+/* `frames` back-to-back periods of the coefficient stream (the streaming-frame workload:
+ * ENABLE held for frames * 2^phi_width clocks).  One period is computed, then replicated by a
+ * store-only kernel: d_out holds frames * 2^phi_width int32. */
+int bhw_generate_batched_device(const bhw_params *p, int device, void *hip_stream,
+                                uint32_t frames, int32_t *d_out);
+
+/* Replaces cordic() alone: cpp/cordic_sincos.cpp:10 (model CPP), hls/cordic/cordic.cpp:45
+ * (model HLS), the cordic_dds entity src/cordic_dds.vhd:77-92 (model VHDL), or taylor_sincos
+ * src/taylor_sincos.vhd:64-80 (sin_type TAYLOR).  Either output pointer may be NULL. */
+int bhw_sincos_device(const bhw_params *p, int device, void *hip_stream,
+                      uint64_t theta0, uint64_t count, int32_t *d_sin, int32_t *d_cos);
+
+/* Convenience for host consumers (file writers, testbenches): runs bhw_generate_device into
+ * library scratch on `device`, then copies the result to host memory.  Synchronous. */
+int bhw_generate_to_host(const bhw_params *p, int device, uint64_t n0, uint64_t count, int32_t *h_out);
+int bhw_sincos_to_host(const bhw_params *p, int device, uint64_t theta0, uint64_t count,
+                       int32_t *h_sin, int32_t *h_cos);
+
+/* Releases the library-owned per-device scratch. */
+int bhw_release_device(int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BHW_H */

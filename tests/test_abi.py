@@ -1,0 +1,137 @@
+"""C-ABI library checks that need no GPU: it loads, exports every declared symbol, validates parameters
+like the reference's parameter surface, and derives the same host-side constants as the oracle."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import oracle_lib as O
+from blackman_harris_win_amd import binding as B
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = B.lib()
+    assert L.bhw_abi_version() == 1
+    header = open(os.path.join(ROOT, "include", "bhw.h")).read()
+    declared = set(re.findall(r"\b(bhw_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(B.ABI_SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_struct_layout_matches_header():
+    assert ctypes.sizeof(B.BhwParams) == 4 * 10 + 4 * 7
+    assert ctypes.sizeof(B.BhwExec) == 24
+
+
+def test_strerror():
+    L = B.lib()
+    assert L.bhw_strerror(0) == b"ok"
+    assert b"unsupported" in L.bhw_strerror(-2)
+
+
+def test_constant_tables_match_oracle_closed_form():
+    t2, t4, g46, g47 = O.tables()
+    a2, g = B.constant_tables(0)
+    a4, _ = B.constant_tables(1)
+    assert a2 == t2 and a4 == t4 and g == [g46, g47]
+
+
+@pytest.mark.parametrize("win", [1, 2, 3, 4, 5, 7])
+@pytest.mark.parametrize("w", [8, 12, 16, 24, 31, 32])
+def test_coeffs_from_float_match_oracle(win, w):
+    assert B.coeffs_from_float(win, w) == O.coeffs(win, w)
+    custom = [0.3635819, 0.4891775, 0.1365995, 0.0106411, 0.001, 0.0002, 0.00001][: O.TERMS[win]]  # Blackman-Nuttall-ish
+    assert B.coeffs_from_float(win, w, custom) == O.coeffs(win, w, custom)
+
+
+def test_params_init_defaults():
+    p = B.make_params(B.WIN_BH7, 26, 32)
+    assert (p.model, p.combine, p.sin_type, p.n_terms, p.precision, p.lut_size) == (0, 0, 0, 7, 1, 9)
+    assert list(p.aa) == [291220644, 465407608, 234080144, 70636474, 11555467, 826795, 14690]
+    assert p.struct_size == ctypes.sizeof(B.BhwParams)
+
+
+def _rc(p):
+    return B.lib().bhw_params_validate(ctypes.byref(p))
+
+
+def test_validation_errors():
+    L = B.lib()
+    assert L.bhw_params_validate(None) == -1
+    with pytest.raises(B.BhwError):
+        B.make_params(6, 10, 16)                       # unknown win_type
+    p = B.make_params(B.WIN_BH4, 20, 24)
+    assert _rc(p) == 0
+    p.phi_width = 3
+    assert _rc(p) == -1
+    p.phi_width = 31
+    assert _rc(p) == -1
+    p.phi_width, p.dat_width = 20, 33
+    assert _rc(p) == -1
+    p.dat_width = 7
+    assert _rc(p) == -1
+    p.dat_width, p.n_terms = 24, 6
+    assert _rc(p) == -1
+    p.n_terms, p.struct_size = 4, 12
+    assert _rc(p) == -1
+    # HLS model: phi_width > dat_width + 2 is ill-defined upstream -> UNSUPPORTED; CPP / VHDL models accept it
+    p = B.make_params(B.WIN_BH4, 26, 16, validate=False)
+    assert _rc(p) == -2 and b"HLS" in L.bhw_last_error()
+    p.model = B.MODEL_CPP
+    assert _rc(p) == 0
+    p.model, p.precision = B.MODEL_VHDL, 0
+    assert _rc(p) == -1
+    p.precision = 7
+    assert _rc(p) == 0
+    # Taylor exists only for 2-/3-term windows (src/win_selector.vhd:93-135)
+    p = B.make_params(B.WIN_BH4, 12, 16, sin_type=B.SIN_TAYLOR, validate=False)
+    assert _rc(p) == -2
+    p = B.make_params(B.WIN_BH3, 12, 16, sin_type=B.SIN_TAYLOR, lut_size=9)
+    assert _rc(p) == 0
+    p.phi_width = 30                                   # STAGE = 18 > 15
+    assert _rc(p) == -2
+
+
+def test_compute_entry_points_fail_loudly_without_gpu():
+    """No CPU fallback: on a machine without a HIP device every compute call returns BHW_ERR_HIP."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = B.lib()
+    p = B.make_params(B.WIN_HAMMING, 12, 16)
+    buf = (ctypes.c_int32 * 16)()
+    assert L.bhw_generate_to_host(ctypes.byref(p), 0, 0, 16, buf) == -3
+    assert b"no CPU path" in L.bhw_last_error() or b"hip" in L.bhw_last_error().lower()
+    assert L.bhw_sincos_to_host(ctypes.byref(p), 0, 0, 16, buf, None) == -3
+    assert L.bhw_generate_device(ctypes.byref(p), 0, None, 0, 16, ctypes.c_void_p(0x1000)) == -3
+    from blackman_harris_win_amd import WinSelector
+    with pytest.raises(RuntimeError):
+        WinSelector(PHI_WIDTH=10, DAT_WIDTH=16).window()
+
+
+def test_workspace_bytes_and_algo_choice():
+    L = B.lib()
+    p = B.make_params(B.WIN_BH7, 26, 32)
+    assert L.bhw_workspace_bytes(ctypes.byref(p), 0, 1 << 26, B.ALGO_DIRECT) == 0
+    assert L.bhw_workspace_bytes(ctypes.byref(p), 0, 1 << 26, B.ALGO_TABLE) == (1 << 24) * 8
+    assert L.bhw_workspace_bytes(ctypes.byref(p), 0, 1 << 26, B.ALGO_AUTO) == (1 << 24) * 8
+    assert L.bhw_workspace_bytes(ctypes.byref(p), 0, 1 << 16, B.ALGO_AUTO) == 0   # short call: direct
+    p = B.make_params(B.WIN_BH4, 26, 16, model=B.MODEL_CPP)                        # low phase bits dropped
+    assert L.bhw_workspace_bytes(ctypes.byref(p), 0, 1 << 26, B.ALGO_TABLE) == (1 << 14) * 8
+
+
+def test_shard_range_partitions():
+    from blackman_harris_win_amd import shard_range
+    for total in (1 << 26, 1000, 7):
+        for ws in (1, 2, 3, 4, 8):
+            cover = []
+            for r in range(ws):
+                n0, c = shard_range(total, r, ws)
+                cover.append((n0, c))
+            assert cover[0][0] == 0 and sum(c for _, c in cover) == total
+            for (a, ca), (b, _) in zip(cover, cover[1:]):
+                assert a + ca == b

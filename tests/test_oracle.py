@@ -1,0 +1,227 @@
+"""Oracle pinning (CPU): the restatement vs the reference's own outputs, golden vectors and tests."""
+import hashlib
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+REFERENCE = "/root/reference"
+
+
+def _md5(a):
+    return hashlib.md5(np.ascontiguousarray(a, dtype="<i4").tobytes()).hexdigest()
+
+
+# ---- constants ------------------------------------------------------------------------------------
+def test_tables_anchors():
+    t2, t4, g46, g47 = O.tables()
+    assert t2[0] == 0x200000000000 and t2[1] == 0x12E4051D9DF3 and t2[47] == 0
+    assert t4[0] == 0x400000000000 and t4[1] == 0x25C80A3B3BE6 and t4[47] == 0
+    assert g46 == 0x26DD3B6A10D8 and g47 == 0x4DBA76D421AF
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="upstream checkout not present")
+def test_tables_equal_reference_literals():
+    """Closed-form tables == the 48 literals in the reference sources (read as text, data only)."""
+    import re
+    t2, t4, _, _ = O.tables()
+    txt = open(os.path.join(REFERENCE, "cpp", "cordic_sincos.cpp")).read()
+    lits = [int(x, 16) for x in re.findall(r"0x([0-9A-Fa-f]{12})\b", txt.split("lut_table")[1].split("};")[0])]
+    assert lits == t2
+    txt = open(os.path.join(REFERENCE, "hls", "windows", "win_function.cpp")).read()
+    lits = [int(x, 16) for x in re.findall(r"0x([0-9A-Fa-f]{12})\b", txt.split("lut_table")[1].split("};")[0])]
+    assert lits == t4
+    txt = open(os.path.join(REFERENCE, "src", "cordic_dds.vhd")).read()
+    lits = [int(x, 16) for x in re.findall(r'x"([0-9A-Fa-f]{12})"', txt.split("ROM_LUT : rom_array")[1].split(");")[0])]
+    assert lits == t4
+
+
+# ---- model A pinned by the reference itself -----------------------------------------------------------
+def test_model_a_equals_reference_coe_dat(golden, golden_dir):
+    e = golden["coe_cpp_14_12"]
+    sc = np.load(os.path.join(golden_dir, e["file"])).astype(np.int32)
+    s, c = O.sincos(O.oparams(1, 14, 12, model=O.MODEL_CPP), 0, 1 << 14)
+    assert np.array_equal(s, sc[:, 0]) and np.array_equal(c, sc[:, 1])
+    text = "".join("%d %d\n" % (a, b) for a, b in zip(s, c)).encode()   # cpp/cordic_sincos.cpp:138
+    assert hashlib.md5(text).hexdigest() == e["text_md5"] == "b65f091fb2afeeb252aa0bc5728fe46a"
+    assert s.min() == -1025 and s.max() == 1024 and c.min() == -1025 and c.max() == 1024
+
+
+def test_model_a_equals_reference_vectors(golden, golden_dir):
+    names = [k for k in golden if k.startswith("sincos_cpp_")]
+    assert len(names) >= 10
+    for name in names:
+        th, s, c = np.load(os.path.join(golden_dir, golden[name]["file"]))
+        pr = golden[name]["params"]
+        p = O.oparams(1, pr["phi_width"], pr["dat_width"], model=O.MODEL_CPP)
+        for i in range(0, len(th), max(1, len(th) // 600)):
+            so, co = O.sincos(p, int(th[i]), 1)
+            assert (so[0], co[0]) == (s[i], c[i]), (name, int(th[i]))
+
+
+@pytest.mark.skipif(not O.ref_pairs(), reason="oracle/_ref not built")
+def test_model_a_equals_oracle_ref_live():
+    """Live comparison against the reference's compiled cordic() (oracle/_ref)."""
+    rng = np.random.default_rng(7)
+    for pw, w, path in O.ref_pairs():
+        ref = O.RefCordic(path)
+        n = 1 << pw
+        th = np.arange(n) if pw <= 10 else np.unique(np.concatenate([rng.integers(0, n, 400), [0, n // 4, n // 2, n - 1]]))
+        s, c = ref.sweep(th)
+        p = O.oparams(1, pw, w, model=O.MODEL_CPP)
+        for i, t in enumerate(th):
+            so, co = O.sincos(p, int(t), 1)
+            assert (so[0], co[0]) == (s[i], c[i]), (pw, w, int(t))
+
+
+# ---- model B pinned by SURVEY App. B known answers ------------------------------------------------------
+@pytest.mark.parametrize("name", ["C1_hamming_12_16", "C2_bh4_20_24", "C4_bh4_16_24_frame", "bh5_10_24", "bh7_4_16"])
+def test_model_b_known_answers(golden, golden_dir, name):
+    e = golden[name]
+    pr = e["params"]
+    p = O.oparams(0, pr["phi_width"], pr["dat_width"], aa=pr["aa"], n_terms=pr["n_terms"])
+    a = O.generate(p, e["n0"], e["count"])
+    assert _md5(a) == e["md5"]
+    assert int(a.astype(np.int64).sum()) == e["sum"] and int(a.min()) == e["min"] and int(a.max()) == e["max"]
+    if "file" in e:
+        assert np.array_equal(a, np.load(os.path.join(golden_dir, e["file"])))
+    for n, v in e.get("sparse", {}).items():
+        assert int(a[int(n)]) == v
+
+
+def test_model_b_c3_sparse_and_strided(golden):
+    e = golden["C3_bh7_26_32"]
+    p = O.oparams(7, 26, 32)
+    assert list(p.aa) == e["params"]["aa"] == [291220644, 465407608, 234080144, 70636474, 11555467, 826795, 14690]
+    for n, v in e["sparse"].items():
+        assert int(O.generate(p, int(n), 1)[0]) == v
+    step = (1 << 23) // 1024
+    for g in (0, 3, 7):
+        got = [int(O.generate(p, (g << 23) + i * step, 1)[0]) for i in range(0, 1024, 16)]
+        assert got == e["shards"][g]["strided_1024"][::16]
+
+
+def test_hls_builtin_coefficients():
+    # SURVEY 8d parameter sets
+    assert O.coeffs(1, 16)[:2] == [17808, 14959]
+    assert O.coeffs(4, 24)[:4] == [3009413, 4096073, 1185142, 97979]
+    assert O.coeffs(7, 32) == [291220644, 465407608, 234080144, 70636474, 11555467, 826795, 14690]
+
+
+# ---- the reference's own tolerance tests, restated ---------------------------------------------------
+@pytest.mark.parametrize("model", [O.MODEL_HLS, O.MODEL_CPP, O.MODEL_VHDL])
+def test_reference_cordic_tolerance_rule(model):
+    """hls/cordic/cordic_test.cpp:66-93: mean |err| per channel < 10 LSB vs round(2^(W-2) sin/cos)."""
+    pw, w = 10, 16
+    n = 1 << pw
+    s, c = O.sincos(O.oparams(1, pw, w, model=model), 0, n)
+    i = np.arange(n)
+    ts = np.round(2.0 ** (w - 2) * np.sin(2 * i * math.pi / n))
+    tc = np.round(2.0 ** (w - 2) * np.cos(2 * i * math.pi / n))
+    assert np.abs(s - ts).sum() / n < 10 and np.abs(c - tc).sum() / n < 10
+    assert np.abs(s - ts).max() <= 5 and np.abs(c - tc).max() <= 5
+
+
+_COEF = {1: [0.5434783, 1 - 0.5434783], 2: [0.5, 0.5], 3: [0.21, 0.25, 0.04], 4: [0.35875, 0.48829, 0.14128, 0.01168],
+         5: [0.3232153788877343, 0.4714921439576260, 0.1755341299601972, 0.0284969901061499, 0.0012613570882927],
+         7: [0.271220360585039, 0.433444612327442, 0.218004122892930, 0.065785343295606, 0.010761867305342,
+             0.000770012710581, 0.000013680883060]}
+
+
+def ideal_window(win, n):
+    i = np.arange(n)
+    w = np.zeros(n)
+    for k, a in enumerate(_COEF[win]):
+        w += ((-1) ** k) * a * np.cos(2 * k * i * math.pi / n)
+    return w
+
+
+@pytest.mark.parametrize("win", [1, 2, 3, 4, 5, 7])
+def test_reference_window_tolerance_rule(win):
+    """hls/windows/window_test.cpp:93-216: sqrt(sum err^2)/N < 10 vs round((2^(W-shift)-1) * w_float)."""
+    pw, w = 10, 24
+    n = 1 << pw
+    a = O.generate(O.oparams(win, pw, w), 0, n).astype(np.float64)
+    shift = 2 if win in (5, 7) else 1
+    gold = np.round((2.0 ** (w - shift) - 1.0) * ideal_window(win, n))
+    # Hann at 10/24 peaks at a0 + a1 = 2^23, which the win_t store wraps to -2^23 (faithful to the HLS
+    # model; the reference's own check trips on that one sample).  Compare modulo 2^W.
+    err = np.mod(a - gold + 2.0 ** (w - 1), 2.0 ** w) - 2.0 ** (w - 1)
+    assert math.sqrt((err ** 2).sum()) / n < 10
+    assert np.abs(err).max() <= 4
+    if win != 2:
+        assert np.array_equal(err, a - gold)
+
+
+def test_vhdl_rule_matches_ideal_half_amplitude():
+    """with the CORDIC source the VHDL rule yields (A0 - A1/2 cos)/2 for Hamming."""
+    pw, w = 11, 16
+    n = 1 << pw
+    a0, a1 = round(0.5434783 * (2 ** (w - 1) - 1)), round((1 - 0.5434783) * (2 ** (w - 1) - 1))
+    got = O.generate(O.oparams(1, pw, w, model=O.MODEL_VHDL, combine=O.COMBINE_VHDL, aa=[a0, a1]), 0, n)
+    ideal = (a0 - 0.5 * a1 * np.cos(2 * math.pi * np.arange(n) / n)) / 2
+    assert np.abs(got - ideal).max() < 3
+
+
+def test_taylor_close_to_float():
+    for pw, w, L in [(12, 16, 9), (14, 24, 9), (16, 32, 9), (10, 16, 9), (11, 16, 9)]:
+        n = 1 << pw
+        p = O.oparams(1, pw, w, sin_type=O.SIN_TAYLOR, lut_size=L)
+        s, c = O.sincos(p, 0, n)
+        amp = 2.0 ** (w - 1) - 1
+        i = np.arange(n)
+        tol = 4 + amp * (math.pi / 2 ** (L + 1)) ** 2 / 2 * 1.1 if pw - L > 2 else 2
+        assert np.abs(s - amp * np.sin(2 * math.pi * i / n)).max() <= tol
+        assert np.abs(c - amp * np.cos(2 * math.pi * i / n)).max() <= tol
+
+
+# ---- structural facts the kernels rely on -----------------------------------------------------------
+def test_typed_store_wraps_never_fire():
+    """The W+2 / W+P bit wraps of the HLS/VHDL CORDIC never change a value (kernels omit them)."""
+    import ctypes
+    o = O.oracle()
+    ev = ctypes.c_uint64(0)
+    c = np.empty(1, np.int32)
+    s = np.empty(1, np.int32)
+    rng = np.random.default_rng(3)
+    for model, prec in [(O.MODEL_HLS, 1), (O.MODEL_VHDL, 1), (O.MODEL_VHDL, 4)]:
+        for pw, w in [(10, 8), (10, 16), (12, 12), (18, 16), (20, 24), (26, 32), (26, 24), (30, 30), (9, 32)]:
+            if model == O.MODEL_HLS and pw > w + 2:
+                continue
+            n = 1 << pw
+            th = np.arange(n) if pw <= 12 else np.unique(np.concatenate(
+                [rng.integers(0, n, 3000), np.arange(64), n // 4 + np.arange(-64, 64), n // 8 + np.arange(-8, 8)]) % n)
+            for t in th:
+                assert o.bhwo_cordic(model, pw, w, prec, int(t), c.ctypes.data, s.ctypes.data, ctypes.byref(ev)) == 0
+    assert ev.value == 0
+
+
+def test_quadrant_images_share_first_quadrant_result():
+    """cos/sin at theta + j*N/4 are the quadrant-rotated first-quadrant pair (basis of the table strategy)."""
+    for model in (O.MODEL_HLS, O.MODEL_CPP, O.MODEL_VHDL):
+        pw, w = 12, 20
+        n = 1 << pw
+        s, c = O.sincos(O.oparams(1, pw, w, model=model), 0, n)
+        q = n // 4
+        neg = (lambda v: ~v) if model == O.MODEL_CPP else (lambda v: -v)
+        assert np.array_equal(c[q:2 * q], neg(s[:q])) and np.array_equal(s[q:2 * q], c[:q])
+        assert np.array_equal(c[2 * q:3 * q], neg(c[:q])) and np.array_equal(s[2 * q:3 * q], neg(s[:q]))
+        assert np.array_equal(c[3 * q:], s[:q]) and np.array_equal(s[3 * q:], neg(c[:q]))
+
+
+def test_stream_is_periodic():
+    p = O.oparams(4, 8, 16)
+    a = O.generate(p, 0, 256)
+    assert np.array_equal(O.generate(p, 256 * 5 + 17, 100), np.concatenate([a, a])[17:117])
+
+
+def test_oracle_rejects_bad_params():
+    with pytest.raises(ValueError):
+        O.generate(O.oparams(4, 26, 16), 0, 4)        # HLS model: PW > W + 2
+    with pytest.raises(ValueError):
+        O.generate(O.oparams(4, 10, 16, n_terms=6), 0, 4)
+    with pytest.raises(ValueError):
+        O.generate(O.oparams(5, 10, 16, sin_type=O.SIN_TAYLOR), 0, 4)
