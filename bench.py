@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: window Gsamples/s + fraction of the HBM-write roofline,
+Blackman-Harris 7-term, N = 2^26 (64M points), 32-bit output (BASELINE.json configs[2]).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  A step = one pass of the hot path over one batch: 2^26 coefficients generated
+from the parameter set into a resident HBM buffer (no inputs; nothing cached between steps: the
+shared CORDIC table is rebuilt inside every step).  With N ranks the coefficient stream is sharded by
+contiguous index range -- rank r produces stream indices [r*2^26, (r+1)*2^26) -- with no data-path
+collective (weak scaling: fixed work per GPU).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PHI_WIDTH, DAT_WIDTH, WIN = 26, 32, 7
+COUNT = 1 << PHI_WIDTH
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3-6.9 achievable)
+BYTES_PER_COEFF = 4          # 4 bytes written per coefficient, 0 read
+
+
+def shard_for(rank):
+    """Contiguous stream-index shard of this rank (weak scaling: COUNT per rank)."""
+    return rank * COUNT, COUNT
+
+
+def timed_steps(step_fn, steps, warmup, barrier, sync, allreduce_max):
+    """The measurement protocol of the bench contract: W untimed steps, then exactly K steps bracketed by
+    barrier + device sync on both sides; returns the MAX over ranks of the elapsed seconds."""
+    for _ in range(warmup):
+        step_fn()
+    sync()
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    sync()
+    barrier()
+    t1 = time.perf_counter()
+    return allreduce_max(t1 - t0)
+
+
+def cpu_baseline(target_seconds=12.0, max_threads=16):
+    """The reference's own cordic() (oracle/_ref, built from cpp/cordic_sincos.cpp) timed on this host's
+    cores on a bounded sample of the same workload; falls back to the oracle port when _ref is absent."""
+    import numpy as np
+    import oracle_lib as O
+    so = os.path.join(ROOT, "oracle", "libcpubaseline.so")
+    if not os.path.exists(so):
+        return None
+    L = ctypes.CDLL(so)
+    L.bhw_cpu_baseline.restype = ctypes.c_double
+    L.bhw_cpu_baseline.argtypes = [ctypes.c_char_p, ctypes.POINTER(O.OParams), ctypes.c_uint64, ctypes.c_uint64,
+                                   ctypes.c_int, ctypes.c_void_p]
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(avail, max_threads))   # the GPU box's CPU share for one GPU is 16 cores
+    ref = os.path.join(ROOT, "oracle", "_ref", f"libref_cordic_{PHI_WIDTH}_{DAT_WIDTH}.so")
+    kind = "reference" if os.path.exists(ref) else "port"
+    # the reference cordic() is model CPP (cpp/cordic_sincos.cpp); same loop and widths as the HLS model
+    p = O.oparams(WIN, PHI_WIDTH, DAT_WIDTH, model=O.MODEL_CPP if kind == "reference" else O.MODEL_HLS)
+    lib = ref.encode() if kind == "reference" else None
+    n0 = COUNT // 4 - (1 << 16)
+    probe = 1 << 17
+    buf = np.empty(probe, np.int32)
+    dt = L.bhw_cpu_baseline(lib, ctypes.byref(p), n0, probe, threads, buf.ctypes.data)
+    if dt <= 0:
+        return None
+    count = int(min(COUNT, max(probe, probe * target_seconds / dt)))
+    buf = np.empty(count, np.int32)
+    dt = L.bhw_cpu_baseline(lib, ctypes.byref(p), n0, count, threads, buf.ctypes.data)
+    # sanity: the harness around the reference cordic() agrees with the oracle on the head of the sample
+    ok = bool(np.array_equal(buf[:2048], O.generate(p, n0, 2048)))
+    what = ("6 calls of cordic() of cpp/cordic_sincos.cpp (compiled from the reference source at PHASE_WIDTH 26 / "
+            "DATA_WIDTH 32) + HLS cosine-sum per coefficient") if kind == "reference" else "oracle C restatement (model HLS)"
+    return {"value": count / dt / 1e9, "unit": "Gsamples/s", "cores": threads, "kind": kind,
+            "sample": f"{count} coefficients of the same BH-7 2^26/32-bit window from n0={n0}, {dt:.2f} s wall, {what}",
+            "matches_oracle": ok}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--algo", default="auto", choices=["auto", "direct", "table"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    args = ap.parse_args()
+
+    import torch
+    import blackman_harris_win_amd as bhw
+    from blackman_harris_win_amd import binding as B
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the generator has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm; used for barrier/max only
+
+    algo = {"auto": B.ALGO_AUTO, "direct": B.ALGO_DIRECT, "table": B.ALGO_TABLE}[args.algo]
+    params = bhw.make_params(WIN, PHI_WIDTH, DAT_WIDTH)          # model HLS + HLS combine + built-in a_k
+    n0, count = shard_for(rank)
+    out = torch.empty(count, dtype=torch.int32, device=dev)
+    ws_bytes = B.lib().bhw_workspace_bytes(ctypes.byref(params), n0, count, algo)
+    workspace = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+
+    def step():
+        bhw.generate(params, n0, count, out=out, algo=algo, workspace=workspace if ws_bytes else None)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def allreduce_max(v):
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # device-side duration of the K steps on the launch stream (HIP events), for the roofline figure
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    state = {"n": 0}
+
+    def step_with_events():
+        if state["n"] == 0:
+            ev0.record()
+        step()
+        state["n"] += 1
+        if state["n"] == args.steps:
+            ev1.record()
+
+    for _ in range(args.warmup):
+        step()
+    elapsed = timed_steps(step_with_events, args.steps, 0, barrier, torch.cuda.synchronize, allreduce_max)
+    dev_ms = ev0.elapsed_time(ev1) / args.steps
+    dev_ms = allreduce_max(dev_ms)
+
+    # parity spot-check outside the timed region (the full check is tests/test_gpu_parity.py)
+    import numpy as np
+    import oracle_lib as O
+    po = O.from_bhw(params)
+    idx = [0, 1, 12345, COUNT // 4, COUNT // 2, COUNT - 1]
+    parity = all(int(out[i]) == int(O.generate(po, n0 + i, 1)[0]) for i in idx)
+    head = np.array_equal(out[:4096].cpu().numpy(), O.generate(po, n0, 4096))
+    parity = bool(parity and head)
+
+    total = world * args.steps * count
+    value = total / elapsed / 1e9
+    achieved = BYTES_PER_COEFF * count / (dev_ms * 1e-3) / 1e9
+    rec = {
+        "metric": "window Gsamples/s (BH-7, N=2^26, 32-bit) + fraction of HBM-write roofline",
+        "value": value, "unit": "Gsamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: Blackman-Harris 7-term, N=2^26 (64M), 32-bit output, model HLS CORDIC + HLS cosine-sum",
+                   "phi_width": PHI_WIDTH, "dat_width": DAT_WIDTH, "n_terms": 7, "coefficients_per_step_per_gpu": count,
+                   "strategy": args.algo, "sharding": "contiguous stream-index range per rank, no collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "device_ms_per_step": dev_ms,
+                     "note": "achieved = 4 B x 2^26 coefficients / device time of one step (all kernels of the step, HIP events on the launch stream)"},
+        "parity_spot_check": parity,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        rec["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.cpu_threads)
+    elif rank == 0:
+        rec["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(rec), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

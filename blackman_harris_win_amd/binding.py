@@ -58,6 +58,13 @@ def lib():
         raise ImportError(
             f"{path} is missing: build it with `python -m blackman_harris_win_amd._build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    # torch owns the device memory and streams handed to the ABI, so its HIP runtime must be the one this
+    # process uses: import it before libbhw.so pulls in libamdhip64 (two runtimes in one process do not
+    # share devices or pointers).  A C/C++ host that links libbhw.so directly needs no torch.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(path)
     P = ctypes.POINTER(BhwParams)
     u32, u64, i32p, vp, ci = ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int
