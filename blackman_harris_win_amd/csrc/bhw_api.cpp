@@ -272,8 +272,23 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
         rc = ensure_scratch(device, need, &ws);
         if (rc) return rc;
     }
+    const uint64_t N = 1ull << p->phi_width;
+    const bool whole = (n0 % N == 0 && count % N == 0);
+    const bool tiled = whole && bhwk_tile_applicable(c, w);
+    c.tab_split = tiled ? 1u : 0u;
     int e = bhwk_table_build(l, c, (int32_t *)ws);
     if (e) return fail_hip(e, "table build launch");
+    if (whole) {
+        // whole periods: quadrant-fold combine for the first, store-only replication for the rest
+        e = tiled ? bhwk_table_combine_tile(l, c, w, (const int32_t *)ws, d_out)
+                  : bhwk_table_combine_fold(l, c, w, (const int32_t *)ws, d_out);
+        if (e) return fail_hip(e, "table combine (fold) launch");
+        if (count > N) {
+            e = bhwk_replicate(l, d_out, N, (uint32_t)(count / N - 1), d_out + N);
+            if (e) return fail_hip(e, "replicate launch");
+        }
+        return BHW_OK;
+    }
     e = bhwk_table_combine(l, c, w, (const int32_t *)ws, n0, count, d_out);
     return e ? fail_hip(e, "table combine launch") : BHW_OK;
 }

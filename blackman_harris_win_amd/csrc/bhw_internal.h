@@ -20,6 +20,8 @@ struct BhwCordicCfg {
     uint32_t out_shr;     // 2 (HLS, CPP) or PRECISION (VHDL)
     uint32_t ones_neg;    // 1: quadrant map negates with ~v (CPP); 0: -v
     uint32_t wide;        // 1: state needs more than 32 bits
+    uint32_t tab_split;   // table layout: 0 natural index u; 1 split by residue class (u%4==0 | u%4==2 | u odd)
+    uint32_t pad_;
 };
 
 // Cosine-sum stage.
@@ -54,6 +56,11 @@ int bhwk_replicate(const BhwLaunch &l, const int32_t *d_frame, uint64_t frame_le
 int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table /* (c,s) pairs, 2^(PW-2) */);
 int bhwk_table_combine(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table,
                        uint64_t n0, uint64_t count, int32_t *d_out);
+// whole period [0, 2^PW) via the quadrant fold (one lane per four coefficients)
+int bhwk_table_combine_fold(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out);
+// whole period, 15-block super-tiles over the residue-split table (z_shr == 0 only)
+int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out);
+bool bhwk_tile_applicable(const BhwCordicCfg &c, const BhwWinCfg &w);
 int bhwk_taylor_window(const BhwLaunch &l, const BhwTaylorCfg &t, const BhwWinCfg &w,
                        uint64_t n0, uint64_t count, int32_t *d_out);
 int bhwk_taylor_sincos(const BhwLaunch &l, const BhwTaylorCfg &t, uint64_t theta0, uint64_t count,

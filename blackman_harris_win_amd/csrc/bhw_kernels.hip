@@ -66,6 +66,16 @@ __device__ __forceinline__ int64_t wrap_bits(int64_t v, uint32_t bits)
     return (int64_t)((uint64_t)v << sh) >> sh;
 }
 
+// Table layouts.  Natural: entry u at index u.  Split: the table is stored as three runs
+//   [ u % 4 == 0 | u % 4 == 2 | u odd ]  so that the even harmonics (t = 2r, 4r, 6r only ever touch even /
+// multiple-of-4 entries) read dense runs instead of every 2nd / 4th entry of a line.
+__device__ __forceinline__ uint32_t tab_index(uint32_t u, uint32_t log2_entries, uint32_t split)
+{
+    if (!split) return u;
+    const uint32_t e = 1u << log2_entries;
+    return (u & 1u) ? (e >> 1) + (u >> 1) : (u & 2u) ? (e >> 2) + (u >> 2) : (u >> 2);
+}
+
 // Accumulate one harmonic.  HLS rule: hls/windows/win_function.cpp:368-375;
 // VHDL rule: src/bh_win_7term.vhd:353-402 (slice, round) -- SURVEY App. A.4/A.6.
 __device__ __forceinline__ void combine_term(int64_t &acc, int32_t a, int32_t cosv, uint32_t k, uint32_t W, uint32_t combine)
@@ -155,7 +165,117 @@ __global__ __launch_bounds__(kBlock) void k_table_build(BhwCordicCfg cfg, uint32
     if (u >= entries) return;
     T x, y;
     cordic_q1<T>(lut_s, (T)cfg.x0, (T)((T)u << cfg.z_shl), (int)cfg.n_iter, x, y);
-    table[u] = make_int2((int32_t)(x >> cfg.out_shr), (int32_t)(y >> cfg.out_shr));
+    table[tab_index(u, cfg.phi_width - 2 - cfg.z_shr, cfg.tab_split)] = make_int2((int32_t)(x >> cfg.out_shr), (int32_t)(y >> cfg.out_shr));
+}
+
+// ---------------------------------------------------------------------------------------
+// Table strategy, pass 1, shared-prefix form.
+//
+// Leaves u (table entries) are contiguous in angle: z0(u) = u << z_shl.  At rotation k every leaf of
+// a group takes the same decision as long as sign(z_k) agrees at the group's two end leaves (z_k is
+// the same affine function of u for all of them), and then (x_k, y_k) is one value for the group.
+//   phase 1: one lane per group of 64 leaves runs the chain from k = 1 until the first rotation at
+//            which the group's end leaves disagree (or kPrefixMax), and parks (x, y, z_first, k) in LDS;
+//   phase 2: each wave takes a group, broadcasts the parked state, and runs only the remaining
+//            rotations with one lane per leaf.
+// Rotation step in "mad" form (x, y 64-bit; z 32-bit; sg = +1 / -1 = the decision):
+//   x += (-sg) * lo32(y >> k);  y += sg * lo32(x >> k)      -> v_ashrrev_i64 / v_mad_i64_i32
+//   z += (-sg) * lut[k]                                       -> v_mad_i32_i24 once lut[k] < 2^23
+// Valid when |x|,|y| < 2^33 and the quarter circle <= 2^32 (all models at W <= 32; VHDL: W+P <= 34):
+// rotation 0 always adds (z0 >= 0), giving x1 = y1 = x0 and z1 = z0 - lut[0], which fits int32.
+// ---------------------------------------------------------------------------------------
+constexpr int kPrefixMax = 20;      // deepest rotation a 64-leaf group is followed to in phase 1
+constexpr int kGroupsPerWg = 256;   // one group per thread in phase 1
+
+struct BhwBuildPlan {
+    uint32_t lut[32];    // the rescaled ROM as 32-bit words (entries fit: quarter circle <= 2^32)
+    uint32_t entries;    // 2^(PW-2-z_shr), a multiple of 64
+    uint32_t n_iter;
+    uint32_t z_shl;
+    uint32_t out_shr;
+    uint32_t log2_entries;
+    uint32_t tab_split;
+    int64_t  x0;
+};
+
+// lut[k] < 2^23 for every k >= 9 whenever the fast path is legal (lut[k] <= atan(2^-k) 2^33 / pi), so the
+// z update is one v_mad_i32_i24 there; earlier rotations use the three-op form.
+constexpr int kMad24From = 9;
+
+__device__ __forceinline__ void rot_step(int64_t &x, int64_t &y, int32_t &z, int k, uint32_t lutk)
+{
+    const int32_t m = z >> 31;                 // -1 when z < 0
+    const int32_t sg = m | 1;                  // decision: -1 rotate back, +1 rotate forward
+    const int32_t nsg = -sg;
+    int32_t ys = (int32_t)(y >> k);
+    int32_t xs = (int32_t)(x >> k);
+    asm volatile("" : "+v"(ys), "+v"(xs));     // both shifts read the old state before either update lands
+    x += (int64_t)nsg * (int64_t)ys;
+    y += (int64_t)sg * (int64_t)xs;
+    if (k >= kMad24From) z += __mul24(nsg, (int32_t)lutk);
+    else                 z = (int32_t)((uint32_t)z - lutk + ((2u * lutk) & (uint32_t)m));
+}
+
+template <int NITER>
+__global__ __launch_bounds__(kGroupsPerWg) void k_table_build_shared(BhwBuildPlan plan, int2 *__restrict__ table)
+{
+    __shared__ int64_t gx[kGroupsPerWg];
+    __shared__ int64_t gy[kGroupsPerWg];
+    __shared__ int32_t gz[kGroupsPerWg];
+    __shared__ int32_t gk[kGroupsPerWg];
+    __shared__ uint32_t lut_s[32];
+    if (threadIdx.x < 32) lut_s[threadIdx.x] = plan.lut[threadIdx.x];
+    __syncthreads();
+
+    constexpr int n_iter = NITER;
+    const uint32_t s = plan.z_shl;
+    const uint32_t group0 = blockIdx.x * kGroupsPerWg;
+    const uint32_t n_groups = plan.entries >> 6;
+
+    // ---- phase 1: shared prefix of each 64-leaf group ----
+    {
+        const uint32_t g = group0 + threadIdx.x;
+        const uint32_t u_first = g << 6;
+        int64_t x = plan.x0, y = plan.x0;                                        // after rotation 0
+        int32_t zf = (int32_t)((u_first << s) - lut_s[0]);
+        const uint32_t span = 63u << s;                                          // z_last - z_first
+        int k = 1;
+        bool live = g < n_groups;
+        const int kmax = n_iter < kPrefixMax ? n_iter : kPrefixMax;
+        for (int kk = 1; kk < kmax; ++kk) {
+            if (live) {
+                const int32_t zl = (int32_t)((uint32_t)zf + span);
+                if ((zf < 0) != (zl < 0)) {
+                    live = false;                                                // the group splits at rotation kk
+                } else {
+                    rot_step(x, y, zf, kk, lut_s[kk]);
+                    k = kk + 1;
+                }
+            }
+        }
+        gx[threadIdx.x] = x;
+        gy[threadIdx.x] = y;
+        gz[threadIdx.x] = zf;
+        gk[threadIdx.x] = k;
+    }
+    __syncthreads();
+
+    // ---- phase 2: one wave per group, one lane per leaf, remaining rotations only ----
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t gi = wave; gi < (uint32_t)kGroupsPerWg; gi += kGroupsPerWg / 64) {
+        const uint32_t g = group0 + gi;
+        if (g >= n_groups) break;
+        int64_t x = gx[gi], y = gy[gi];
+        int32_t z = (int32_t)((uint32_t)gz[gi] + (lane << s));
+        const int k0 = __builtin_amdgcn_readfirstlane(gk[gi]);
+        // Fully unrolled: every shift is an immediate and every lut entry a scalar kernel argument; k0 is
+        // wave-uniform, so each guard is one scalar compare-and-branch.
+#pragma unroll
+        for (int k = 1; k < NITER; ++k) {
+            if (k >= k0) rot_step(x, y, z, k, plan.lut[k]);
+        }
+        table[tab_index((g << 6) + lane, plan.log2_entries, plan.tab_split)] = make_int2((int32_t)(x >> plan.out_shr), (int32_t)(y >> plan.out_shr));
+    }
 }
 
 // Table strategy, pass 2 (general form): one lane per coefficient, K-1 gathers.
@@ -171,12 +291,142 @@ __global__ __launch_bounds__(kBlock) void k_table_combine(BhwCordicCfg cfg, BhwW
     int64_t acc = win.aa[0];
     for (uint32_t k = 1; k < win.n_terms; ++k) {
         const uint32_t theta = (k * n) & mask;
-        const int2 cs = table[(theta & tmask) >> cfg.z_shr];
+        const int2 cs = table[tab_index((theta & tmask) >> cfg.z_shr, pw - 2 - cfg.z_shr, cfg.tab_split)];
         int32_t c, s;
         quadrant_map(theta >> (pw - 2), cs.x, cs.y, cfg.ones_neg, c, s);
         combine_term(acc, win.aa[k], c, k, cfg.dat_width, win.combine);
     }
     out[i] = combine_final(acc, cfg.dat_width, win.combine, win.n_terms);
+}
+
+// Table strategy, pass 2, whole-period form ("quadrant fold").  Lane r in [0, N/4) owns the four
+// coefficients n = r + j*N/4.  For harmonic k their phases k*n = k*r + j*k*N/4 differ only in the
+// quadrant field, which every model applies AFTER the rotation (win_function.cpp:86-88,135-150 |
+// cordic_sincos.cpp:25,70-86 | cordic_dds.vhd:170-172,232-246), so one (c, s) gather serves all four.
+__global__ __launch_bounds__(kBlock) void k_table_combine_fold(BhwCordicCfg cfg, BhwWinCfg win, const int2 *__restrict__ table,
+                                                                int32_t *__restrict__ out)
+{
+    const uint32_t pw = cfg.phi_width;
+    const uint32_t quarter = 1u << (pw - 2);
+    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= quarter) return;
+    const uint32_t mask = (pw >= 32) ? 0xFFFFFFFFu : ((1u << pw) - 1u);
+    const uint32_t tmask = quarter - 1u;
+    const uint32_t W = cfg.dat_width;
+    int64_t acc0 = win.aa[0], acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    for (uint32_t k = 1; k < win.n_terms; ++k) {
+        const uint32_t theta = (k * r) & mask;
+        const uint32_t q = theta >> (pw - 2);
+        const int2 cs = table[tab_index((theta & tmask) >> cfg.z_shr, pw - 2 - cfg.z_shr, cfg.tab_split)];
+        const int32_t nc = cfg.ones_neg ? ~cs.x : -cs.x;
+        const int32_t ns = cfg.ones_neg ? ~cs.y : -cs.y;
+        // cosine in quadrant 0..3: c, -s, -c, s
+        int64_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+        combine_term(p0, win.aa[k], cs.x, 0, W, win.combine);
+        combine_term(p1, win.aa[k], ns, 0, W, win.combine);
+        combine_term(p2, win.aa[k], nc, 0, W, win.combine);
+        combine_term(p3, win.aa[k], cs.y, 0, W, win.combine);
+        if (k & 1u) { p0 = -p0; p1 = -p1; p2 = -p2; p3 = -p3; }
+        // image j sits in quadrant (q + j*k) & 3
+        const uint32_t q0 = q, q1 = (q + k) & 3u, q2 = (q + 2u * k) & 3u, q3 = (q + 3u * k) & 3u;
+        acc0 += q0 == 0 ? p0 : q0 == 1 ? p1 : q0 == 2 ? p2 : p3;
+        acc1 += q1 == 0 ? p0 : q1 == 1 ? p1 : q1 == 2 ? p2 : p3;
+        acc2 += q2 == 0 ? p0 : q2 == 1 ? p1 : q2 == 2 ? p2 : p3;
+        acc3 += q3 == 0 ? p0 : q3 == 1 ? p1 : q3 == 2 ? p2 : p3;
+    }
+    out[r] = combine_final(acc0, W, win.combine, win.n_terms);
+    out[r + quarter] = combine_final(acc1, W, win.combine, win.n_terms);
+    out[r + 2u * quarter] = combine_final(acc2, W, win.combine, win.n_terms);
+    out[r + 3u * quarter] = combine_final(acc3, W, win.combine, win.n_terms);
+}
+
+// ---------------------------------------------------------------------------------------
+// Table strategy, pass 2, super-tile form (z_shr == 0).
+//
+// Lane r gathers entry t_k = k*r mod E (E = N/4) for harmonic k.  A run of consecutive r therefore
+// reads every k-th entry of a span, and the other k-1 residues of that span are wanted by the runs
+// r + i*inv(k) mod E.  A workgroup takes the 15 runs  r0 + i3*inv3 + i5*inv5 + [0, B)  together: for
+// k = 3 the three i3-siblings interleave into one dense span, for k = 5 the five i5-siblings do, k = 6
+// reads E[3r'] (dense for the same reason), k = 1, 2, 4 are dense in the split layout on their own.
+// Every table line is then fetched for entries that are all used, instead of 1/k of them.
+// The 15 run offsets are ~E/15 apart, so tiles m = 0..n_tiles-1 cover the ring once; the few entries
+// covered twice at the seams are recomputed with identical results (idempotent stores).
+// ---------------------------------------------------------------------------------------
+constexpr int kTileThreads = 128;
+
+struct BhwTilePlan {
+    uint32_t offs[15];   // (i3*inv3 + i5*inv5) mod E, index i3 + 3*i5
+    uint32_t n_tiles;
+};
+
+template <int K>
+__device__ __forceinline__ void tile_harmonic(const BhwCordicCfg &cfg, const int32_t a, const uint32_t W, const uint32_t combine,
+                                              const int2 cs, const uint32_t q, int64_t (&acc)[4])
+{
+    const int32_t nc = cfg.ones_neg ? ~cs.x : -cs.x;
+    const int32_t ns = cfg.ones_neg ? ~cs.y : -cs.y;
+    int64_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;               // cosine term in quadrant 0..3: c, -s, -c, s
+    combine_term(p0, a, cs.x, K, W, combine);
+    combine_term(p1, a, ns, K, W, combine);
+    combine_term(p2, a, nc, K, W, combine);
+    combine_term(p3, a, cs.y, K, W, combine);
+    // rotate the four candidates by q so that image j (quadrant q + j*K) reads a fixed slot
+    const bool b0 = q & 1u, b1 = q & 2u;
+    const int64_t r0 = b0 ? p1 : p0, r1 = b0 ? p2 : p1, r2 = b0 ? p3 : p2, r3 = b0 ? p0 : p3;
+    const int64_t s0 = b1 ? r2 : r0, s1 = b1 ? r3 : r1, s2 = b1 ? r0 : r2, s3 = b1 ? r1 : r3;
+    const int64_t sv[4] = {s0, s1, s2, s3};
+    acc[0] += sv[0];
+    acc[1] += sv[K & 3];
+    acc[2] += sv[(2 * K) & 3];
+    acc[3] += sv[(3 * K) & 3];
+}
+
+template <int NB, typename AccT>
+__global__ __launch_bounds__(kTileThreads) void k_table_combine_tile(BhwCordicCfg cfg, BhwWinCfg win, BhwTilePlan tp,
+                                                                      const int2 *__restrict__ table, int32_t *__restrict__ out)
+{
+    const uint32_t lq = cfg.phi_width - 2;
+    const uint32_t E = 1u << lq, emask = E - 1u;
+    const uint32_t mask = (cfg.phi_width >= 32) ? 0xFFFFFFFFu : ((1u << cfg.phi_width) - 1u);
+    const uint32_t W = cfg.dat_width;
+    const uint32_t rbase = blockIdx.x * kTileThreads + threadIdx.x;
+    AccT acc[NB][4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[b][j] = (AccT)win.aa[0];
+
+#define BHW_TILE_HARMONIC(K)                                                                             \
+    if (win.n_terms > K) {                                                                               \
+        int2 cs[NB];                                                                                     \
+        uint32_t qq[NB];                                                                                 \
+        _Pragma("unroll") for (int b = 0; b < NB; ++b) {                                                 \
+            const uint32_t r = (rbase + tp.offs[b]) & emask;                                             \
+            const uint32_t theta = ((uint32_t)K * r) & mask;                                             \
+            qq[b] = theta >> lq;                                                                         \
+            cs[b] = table[tab_index(theta & emask, lq, cfg.tab_split)];                                  \
+        }                                                                                                \
+        _Pragma("unroll") for (int b = 0; b < NB; ++b) {                                                 \
+            int64_t d[4] = {0, 0, 0, 0};                                                                 \
+            tile_harmonic<K>(cfg, win.aa[K], W, win.combine, cs[b], qq[b], d);                           \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[b][j] += (AccT)d[j];                       \
+        }                                                                                                \
+    }
+    BHW_TILE_HARMONIC(1)
+    BHW_TILE_HARMONIC(2)
+    BHW_TILE_HARMONIC(3)
+    BHW_TILE_HARMONIC(4)
+    BHW_TILE_HARMONIC(5)
+    BHW_TILE_HARMONIC(6)
+#undef BHW_TILE_HARMONIC
+
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const uint32_t r = (rbase + tp.offs[b]) & emask;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            out[r + (uint32_t)j * E] = combine_final((int64_t)acc[b][j], W, win.combine, win.n_terms);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -336,6 +586,31 @@ int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table
     BHW_SET_DEVICE(l);
     hipStream_t st = (hipStream_t)l.stream;
     const uint32_t entries = 1u << (c.phi_width - 2 - c.z_shr);
+    // shared-prefix kernel: needs whole 64-leaf groups, |x| < 2^33 and a quarter circle <= 2^32
+    const bool fits = (c.dat_width + c.out_shr <= 34);
+    if (entries >= 64 && fits && c.n_iter >= 2) {
+        BhwBuildPlan plan;
+        for (uint32_t k = 0; k < 32; ++k) plan.lut[k] = (uint32_t)c.lut[k];
+        plan.entries = entries;
+        plan.n_iter = c.n_iter;
+        plan.z_shl = c.z_shl;
+        plan.out_shr = c.out_shr;
+        plan.log2_entries = c.phi_width - 2 - c.z_shr;
+        plan.tab_split = c.tab_split;
+        plan.x0 = c.x0;
+        const unsigned groups = entries >> 6;
+        const dim3 grid((groups + kGroupsPerWg - 1) / kGroupsPerWg), block(kGroupsPerWg);
+        switch (c.n_iter) {
+#define BHW_CASE(N) case N: hipLaunchKernelGGL(k_table_build_shared<N>, grid, block, 0, st, plan, (int2 *)d_table); break;
+            BHW_CASE(7) BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14)
+            BHW_CASE(15) BHW_CASE(16) BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20) BHW_CASE(21) BHW_CASE(22)
+            BHW_CASE(23) BHW_CASE(24) BHW_CASE(25) BHW_CASE(26) BHW_CASE(27) BHW_CASE(28) BHW_CASE(29) BHW_CASE(30)
+            BHW_CASE(31) BHW_CASE(32)
+#undef BHW_CASE
+        default: return (int)hipErrorInvalidValue;
+        }
+        return finish(hipSuccess);
+    }
     if (c.wide) hipLaunchKernelGGL(k_table_build<int64_t>, dim3(grid_for(entries)), dim3(kBlock), 0, st, c, entries, (int2 *)d_table);
     else        hipLaunchKernelGGL(k_table_build<int32_t>, dim3(grid_for(entries)), dim3(kBlock), 0, st, c, entries, (int2 *)d_table);
     return finish(hipSuccess);
@@ -348,6 +623,69 @@ int bhwk_table_combine(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCf
     BHW_SET_DEVICE(l);
     hipStream_t st = (hipStream_t)l.stream;
     hipLaunchKernelGGL(k_table_combine, dim3(grid_for(count)), dim3(kBlock), 0, st, c, w, (const int2 *)d_table, n0, count, d_out);
+    return finish(hipSuccess);
+}
+
+int bhwk_table_combine_fold(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out)
+{
+    BHW_SET_DEVICE(l);
+    hipStream_t st = (hipStream_t)l.stream;
+    const uint32_t quarter = 1u << (c.phi_width - 2);
+    hipLaunchKernelGGL(k_table_combine_fold, dim3(grid_for(quarter)), dim3(kBlock), 0, st, c, w, (const int2 *)d_table, d_out);
+    return finish(hipSuccess);
+}
+
+
+static uint32_t inv_mod_pow2(uint32_t a, uint32_t log2m)
+{
+    uint32_t x = a;                      // Newton iteration: x <- x (2 - a x), doubles the correct bits
+    for (int i = 0; i < 6; ++i) x *= 2u - a * x;
+    return log2m >= 32 ? x : (x & ((1u << log2m) - 1u));
+}
+
+bool bhwk_tile_applicable(const BhwCordicCfg &c, const BhwWinCfg &w)
+{
+    (void)w;
+    return c.z_shr == 0 && c.phi_width >= 16 && c.phi_width <= 30;
+}
+
+int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out)
+{
+    BHW_SET_DEVICE(l);
+    hipStream_t st = (hipStream_t)l.stream;
+    const uint32_t lq = c.phi_width - 2, E = 1u << lq;
+    const uint32_t inv3 = inv_mod_pow2(3, lq), inv5 = inv_mod_pow2(5, lq);
+    const int nb3 = w.n_terms > 3 ? 3 : 1, nb5 = w.n_terms > 5 ? 5 : 1;
+    const int nb = nb3 * nb5;
+    BhwTilePlan tp;
+    uint32_t sorted[15];
+    for (int i5 = 0; i5 < nb5; ++i5)
+        for (int i3 = 0; i3 < nb3; ++i3) {
+            const uint32_t o = (uint32_t)(((uint64_t)i3 * inv3 + (uint64_t)i5 * inv5) & (E - 1u));
+            tp.offs[i3 + nb3 * i5] = o;
+            sorted[i3 + nb3 * i5] = o;
+        }
+    for (int i = nb; i < 15; ++i) tp.offs[i] = 0;
+    // tiles needed so that every run class sweeps past the start of the next one around the ring
+    for (int i = 1; i < nb; ++i)
+        for (int j = i; j > 0 && sorted[j - 1] > sorted[j]; --j) { uint32_t t = sorted[j]; sorted[j] = sorted[j - 1]; sorted[j - 1] = t; }
+    uint64_t maxgap = 0;
+    for (int i = 0; i < nb; ++i) {
+        const uint64_t nxt = (i + 1 < nb) ? sorted[i + 1] : (uint64_t)sorted[0] + E;
+        if (nxt - sorted[i] > maxgap) maxgap = nxt - sorted[i];
+    }
+    tp.n_tiles = (uint32_t)((maxgap + kTileThreads - 1) / kTileThreads);
+    const bool acc32 = (w.combine == BHW_COMBINE_HLS) || (c.dat_width + 2 <= 32);
+    const dim3 grid(tp.n_tiles), block(kTileThreads);
+#define BHW_LAUNCH_TILE(NB)                                                                                              \
+    do {                                                                                                                 \
+        if (acc32) hipLaunchKernelGGL((k_table_combine_tile<NB, int32_t>), grid, block, 0, st, c, w, tp, (const int2 *)d_table, d_out); \
+        else       hipLaunchKernelGGL((k_table_combine_tile<NB, int64_t>), grid, block, 0, st, c, w, tp, (const int2 *)d_table, d_out); \
+    } while (0)
+    if (nb == 15) BHW_LAUNCH_TILE(15);
+    else if (nb == 3) BHW_LAUNCH_TILE(3);
+    else BHW_LAUNCH_TILE(1);
+#undef BHW_LAUNCH_TILE
     return finish(hipSuccess);
 }
 

@@ -130,6 +130,25 @@ def test_custom_weights_and_wrapping_sum(torch):
         assert np.array_equal(gpu_generate(p, 0, 1024, algo), O.generate(O.from_bhw(p), 0, 1024))
 
 
+# ---- whole-period calls at PW >= 16 take the super-tile combine (1-, 3- and 15-run tiles; 32/64-bit sums) ----
+TILE_CASES = [(1, 16, 16, B.MODEL_HLS, B.COMBINE_HLS), (3, 16, 24, B.MODEL_HLS, B.COMBINE_VHDL),
+              (4, 17, 24, B.MODEL_CPP, B.COMBINE_HLS), (5, 16, 32, B.MODEL_HLS, B.COMBINE_HLS),
+              (7, 16, 32, B.MODEL_VHDL, B.COMBINE_VHDL), (7, 17, 30, B.MODEL_CPP, B.COMBINE_VHDL),
+              (7, 16, 31, B.MODEL_HLS, B.COMBINE_VHDL), (4, 18, 16, B.MODEL_HLS, B.COMBINE_HLS),
+              (7, 18, 20, B.MODEL_VHDL, B.COMBINE_HLS), (2, 16, 24, B.MODEL_HLS, B.COMBINE_HLS)]
+
+
+@pytest.mark.parametrize("win,pw,w,model,combine", TILE_CASES)
+def test_whole_period_tile_path(torch, win, pw, w, model, combine):
+    p = B.make_params(win, pw, w, model=model, combine=combine)
+    n = 1 << pw
+    want = O.generate(O.from_bhw(p), 0, n)
+    assert np.array_equal(gpu_generate(p, 0, n, B.ALGO_TABLE), want)
+    # two periods: the second is the store-only replica of the first
+    two = gpu_generate(p, n, 2 * n, B.ALGO_TABLE)
+    assert np.array_equal(two[:n], want) and np.array_equal(two[n:], want)
+
+
 # ---- edge cases: empty, ragged, offsets, wrap-around --------------------------------------------------------
 @pytest.mark.parametrize("algo", ALGOS)
 def test_ragged_counts_and_offsets(torch, algo):
