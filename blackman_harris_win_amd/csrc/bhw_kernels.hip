@@ -7,6 +7,7 @@
 //
 // Integer semantics follow SURVEY App. A; reference lines are cited at each step.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "bhw_internal.h"
 
 namespace {
@@ -185,7 +186,8 @@ __global__ __launch_bounds__(kBlock) void k_table_build(BhwCordicCfg cfg, uint32
 // rotation 0 always adds (z0 >= 0), giving x1 = y1 = x0 and z1 = z0 - lut[0], which fits int32.
 // ---------------------------------------------------------------------------------------
 constexpr int kPrefixMax = 20;      // deepest rotation a 64-leaf group is followed to in phase 1
-constexpr int kGroupsPerWg = 256;   // one group per thread in phase 1
+constexpr int kGroupsPerWg = 64;    // phase 1: one group per lane of the first wave
+constexpr int kBuildThreads = 256;  // phase 2: four waves, 16 groups each
 
 struct BhwBuildPlan {
     uint32_t lut[32];    // the rescaled ROM as 32-bit words (entries fit: quarter circle <= 2^32)
@@ -217,7 +219,7 @@ __device__ __forceinline__ void rot_step(int64_t &x, int64_t &y, int32_t &z, int
 }
 
 template <int NITER>
-__global__ __launch_bounds__(kGroupsPerWg) void k_table_build_shared(BhwBuildPlan plan, int2 *__restrict__ table)
+__global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPlan plan, int2 *__restrict__ table)
 {
     __shared__ int64_t gx[kGroupsPerWg];
     __shared__ int64_t gy[kGroupsPerWg];
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(kGroupsPerWg) void k_table_build_shared(BhwBuildPla
     const uint32_t n_groups = plan.entries >> 6;
 
     // ---- phase 1: shared prefix of each 64-leaf group ----
-    {
+    if (threadIdx.x < kGroupsPerWg) {
         const uint32_t g = group0 + threadIdx.x;
         const uint32_t u_first = g << 6;
         int64_t x = plan.x0, y = plan.x0;                                        // after rotation 0
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(kGroupsPerWg) void k_table_build_shared(BhwBuildPla
 
     // ---- phase 2: one wave per group, one lane per leaf, remaining rotations only ----
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    for (uint32_t gi = wave; gi < (uint32_t)kGroupsPerWg; gi += kGroupsPerWg / 64) {
+    for (uint32_t gi = wave; gi < (uint32_t)kGroupsPerWg; gi += kBuildThreads / 64) {
         const uint32_t g = group0 + gi;
         if (g >= n_groups) break;
         int64_t x = gx[gi], y = gy[gi];
@@ -352,64 +354,98 @@ __global__ __launch_bounds__(kBlock) void k_table_combine_fold(BhwCordicCfg cfg,
 // The 15 run offsets are ~E/15 apart, so tiles m = 0..n_tiles-1 cover the ring once; the few entries
 // covered twice at the seams are recomputed with identical results (idempotent stores).
 // ---------------------------------------------------------------------------------------
-constexpr int kTileThreads = 128;
+constexpr int kTileThreads = 256;
+constexpr int kTileLanes = 256;     // tile width; with kTileLanes < kTileThreads the runs are split over thread groups (measured slower)
 
 struct BhwTilePlan {
-    uint32_t offs[15];   // (i3*inv3 + i5*inv5) mod E, index i3 + 3*i5
+    uint32_t offs[16];   // (i3*inv3 + i5*inv5) mod ring, index i3 + 3*i5; padded by repeating the last run
     uint32_t n_tiles;
 };
 
-template <int K>
+// MODE 0: HLS cosine-sum, two's-complement quadrant map, sums kept modulo 2^32 (exact: the result is
+//         wrapped to W <= 32 bits anyway, win_function.cpp:375);  MODE 1: same with the one's-complement map of
+//         the cpp model;  MODE 2: any combine rule, 64-bit sums (the VHDL rule needs W+2 bits).
+template <int K, int MODE>
 __device__ __forceinline__ void tile_harmonic(const BhwCordicCfg &cfg, const int32_t a, const uint32_t W, const uint32_t combine,
-                                              const int2 cs, const uint32_t q, int64_t (&acc)[4])
+                                              const int2 cs, const uint32_t q,
+                                              typename std::conditional<MODE == 2, int64_t, int32_t>::type (&acc)[4])
 {
-    const int32_t nc = cfg.ones_neg ? ~cs.x : -cs.x;
-    const int32_t ns = cfg.ones_neg ? ~cs.y : -cs.y;
-    int64_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;               // cosine term in quadrant 0..3: c, -s, -c, s
-    combine_term(p0, a, cs.x, K, W, combine);
-    combine_term(p1, a, ns, K, W, combine);
-    combine_term(p2, a, nc, K, W, combine);
-    combine_term(p3, a, cs.y, K, W, combine);
+    using acc_t = typename std::conditional<MODE == 2, int64_t, int32_t>::type;
+    acc_t p0, p1, p2, p3;                                  // cosine term in quadrant 0..3: c, -s, -c, s
+    if constexpr (MODE == 2) {
+        const int32_t nc = cfg.ones_neg ? ~cs.x : -cs.x;
+        const int32_t ns = cfg.ones_neg ? ~cs.y : -cs.y;
+        p0 = p1 = p2 = p3 = 0;
+        combine_term(p0, a, cs.x, K, W, combine);
+        combine_term(p1, a, ns, K, W, combine);
+        combine_term(p2, a, nc, K, W, combine);
+        combine_term(p3, a, cs.y, K, W, combine);
+    } else {
+        const int32_t nc = MODE == 1 ? ~cs.x : -cs.x;
+        const int32_t ns = MODE == 1 ? ~cs.y : -cs.y;
+        const uint32_t sh = W - 2;                         // mlt_k = (a_k * c_k) >> (NWIDTH-2), win_function.cpp:368-373
+        const int32_t m0 = (int32_t)(((int64_t)a * cs.x) >> sh), m1 = (int32_t)(((int64_t)a * ns) >> sh);
+        const int32_t m2 = (int32_t)(((int64_t)a * nc) >> sh), m3 = (int32_t)(((int64_t)a * cs.y) >> sh);
+        p0 = (K & 1) ? -m0 : m0;                           // a0 - m1 + m2 - m3 + ...
+        p1 = (K & 1) ? -m1 : m1;
+        p2 = (K & 1) ? -m2 : m2;
+        p3 = (K & 1) ? -m3 : m3;
+    }
     // rotate the four candidates by q so that image j (quadrant q + j*K) reads a fixed slot
     const bool b0 = q & 1u, b1 = q & 2u;
-    const int64_t r0 = b0 ? p1 : p0, r1 = b0 ? p2 : p1, r2 = b0 ? p3 : p2, r3 = b0 ? p0 : p3;
-    const int64_t s0 = b1 ? r2 : r0, s1 = b1 ? r3 : r1, s2 = b1 ? r0 : r2, s3 = b1 ? r1 : r3;
-    const int64_t sv[4] = {s0, s1, s2, s3};
+    const acc_t r0 = b0 ? p1 : p0, r1 = b0 ? p2 : p1, r2 = b0 ? p3 : p2, r3 = b0 ? p0 : p3;
+    const acc_t s0 = b1 ? r2 : r0, s1 = b1 ? r3 : r1, s2 = b1 ? r0 : r2, s3 = b1 ? r1 : r3;
+    const acc_t sv[4] = {s0, s1, s2, s3};
     acc[0] += sv[0];
     acc[1] += sv[K & 3];
     acc[2] += sv[(2 * K) & 3];
     acc[3] += sv[(3 * K) & 3];
 }
 
-template <int NB, typename AccT>
+// Lane r in [0, E/2) owns the eight coefficients n = r + h*E/2 + j*E (h = 0,1; j = 0..3).  For even k the
+// two h-images share one gather (k*E/2 is a whole number of quadrants); for odd k the second image reads
+// entry t + E/2, another dense span of the same tile.
+template <int NB, int MODE>
 __global__ __launch_bounds__(kTileThreads) void k_table_combine_tile(BhwCordicCfg cfg, BhwWinCfg win, BhwTilePlan tp,
                                                                       const int2 *__restrict__ table, int32_t *__restrict__ out)
 {
+    using acc_t = typename std::conditional<MODE == 2, int64_t, int32_t>::type;
     const uint32_t lq = cfg.phi_width - 2;
-    const uint32_t E = 1u << lq, emask = E - 1u;
+    const uint32_t E = 1u << lq, emask = E - 1u, H = E >> 1, hmask = H - 1u;
     const uint32_t mask = (cfg.phi_width >= 32) ? 0xFFFFFFFFu : ((1u << cfg.phi_width) - 1u);
     const uint32_t W = cfg.dat_width;
-    const uint32_t rbase = blockIdx.x * kTileThreads + threadIdx.x;
-    AccT acc[NB][4];
+    // thread group `part` of the workgroup takes runs [part*NR, part*NR + NR) of the tile (registers: NR*8 sums)
+    constexpr int kParts = (NB >= 15) ? kTileThreads / kTileLanes : 1;
+    constexpr int NR = (NB + kParts - 1) / kParts;
+    constexpr int kLanes = kTileThreads / kParts;
+    const uint32_t part = threadIdx.x / kLanes;
+    const uint32_t rbase = blockIdx.x * kLanes + (threadIdx.x % kLanes);
+    const uint32_t *offs = tp.offs + part * NR;        // padded with copies of the last run (idempotent stores)
+    acc_t acc[NR][2][4];
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+    for (int b = 0; b < NR; ++b)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[b][j] = (AccT)win.aa[0];
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[b][h][j] = (acc_t)win.aa[0];
 
 #define BHW_TILE_HARMONIC(K)                                                                             \
     if (win.n_terms > K) {                                                                               \
-        int2 cs[NB];                                                                                     \
-        uint32_t qq[NB];                                                                                 \
-        _Pragma("unroll") for (int b = 0; b < NB; ++b) {                                                 \
-            const uint32_t r = (rbase + tp.offs[b]) & emask;                                             \
-            const uint32_t theta = ((uint32_t)K * r) & mask;                                             \
-            qq[b] = theta >> lq;                                                                         \
-            cs[b] = table[tab_index(theta & emask, lq, cfg.tab_split)];                                  \
+        constexpr int NG = (K & 1) ? 2 : 1;                                                              \
+        int2 cs[NR][NG];                                                                                 \
+        _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
+            const uint32_t r = (rbase + offs[b]) & hmask;                                             \
+            _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                             \
+                const uint32_t theta = ((uint32_t)K * (r + (uint32_t)g * H)) & mask;                     \
+                cs[b][g] = table[tab_index(theta & emask, lq, 1u)];                                      \
+            }                                                                                            \
         }                                                                                                \
-        _Pragma("unroll") for (int b = 0; b < NB; ++b) {                                                 \
-            int64_t d[4] = {0, 0, 0, 0};                                                                 \
-            tile_harmonic<K>(cfg, win.aa[K], W, win.combine, cs[b], qq[b], d);                           \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[b][j] += (AccT)d[j];                       \
+        _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
+            const uint32_t r = (rbase + offs[b]) & hmask;                                             \
+            _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                              \
+                const uint32_t theta = ((uint32_t)K * (r + (uint32_t)h * H)) & mask;                     \
+                tile_harmonic<K, MODE>(cfg, win.aa[K], W, win.combine, cs[b][NG == 2 ? h : 0], theta >> lq, acc[b][h]); \
+            }                                                                                            \
         }                                                                                                \
     }
     BHW_TILE_HARMONIC(1)
@@ -421,11 +457,17 @@ __global__ __launch_bounds__(kTileThreads) void k_table_combine_tile(BhwCordicCf
 #undef BHW_TILE_HARMONIC
 
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const uint32_t r = (rbase + tp.offs[b]) & emask;
+    for (int b = 0; b < NR; ++b) {
+        const uint32_t r = (rbase + offs[b]) & hmask;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            out[r + (uint32_t)j * E] = combine_final((int64_t)acc[b][j], W, win.combine, win.n_terms);
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int32_t v;
+                if constexpr (MODE == 2) v = combine_final((int64_t)acc[b][h][j], W, win.combine, win.n_terms);
+                else v = (int32_t)((uint32_t)acc[b][h][j] << (32u - W)) >> (32u - W);   // (win_t)(...) wrap to W bits
+                out[r + (uint32_t)h * H + (uint32_t)j * E] = v;
+            }
     }
 }
 
@@ -599,7 +641,7 @@ int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table
         plan.tab_split = c.tab_split;
         plan.x0 = c.x0;
         const unsigned groups = entries >> 6;
-        const dim3 grid((groups + kGroupsPerWg - 1) / kGroupsPerWg), block(kGroupsPerWg);
+        const dim3 grid((groups + kGroupsPerWg - 1) / kGroupsPerWg), block(kBuildThreads);
         switch (c.n_iter) {
 #define BHW_CASE(N) case N: hipLaunchKernelGGL(k_table_build_shared<N>, grid, block, 0, st, plan, (int2 *)d_table); break;
             BHW_CASE(7) BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14)
@@ -645,7 +687,8 @@ static uint32_t inv_mod_pow2(uint32_t a, uint32_t log2m)
 
 bool bhwk_tile_applicable(const BhwCordicCfg &c, const BhwWinCfg &w)
 {
-    (void)w;
+    // the 15-run tile with 64-bit sums (VHDL rule at 6+ harmonics) does not fit the register file: plain fold instead
+    if (w.combine != BHW_COMBINE_HLS && w.n_terms > 5) return false;
     return c.z_shr == 0 && c.phi_width >= 16 && c.phi_width <= 30;
 }
 
@@ -653,8 +696,8 @@ int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const Bhw
 {
     BHW_SET_DEVICE(l);
     hipStream_t st = (hipStream_t)l.stream;
-    const uint32_t lq = c.phi_width - 2, E = 1u << lq;
-    const uint32_t inv3 = inv_mod_pow2(3, lq), inv5 = inv_mod_pow2(5, lq);
+    const uint32_t lq = c.phi_width - 2, E = 1u << (lq - 1);   // the lane ring is [0, N/8): each lane owns r and r + N/8
+    const uint32_t inv3 = inv_mod_pow2(3, lq - 1), inv5 = inv_mod_pow2(5, lq - 1);
     const int nb3 = w.n_terms > 3 ? 3 : 1, nb5 = w.n_terms > 5 ? 5 : 1;
     const int nb = nb3 * nb5;
     BhwTilePlan tp;
@@ -665,7 +708,7 @@ int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const Bhw
             tp.offs[i3 + nb3 * i5] = o;
             sorted[i3 + nb3 * i5] = o;
         }
-    for (int i = nb; i < 15; ++i) tp.offs[i] = 0;
+    for (int i = nb; i < 16; ++i) tp.offs[i] = tp.offs[nb - 1];
     // tiles needed so that every run class sweeps past the start of the next one around the ring
     for (int i = 1; i < nb; ++i)
         for (int j = i; j > 0 && sorted[j - 1] > sorted[j]; --j) { uint32_t t = sorted[j]; sorted[j] = sorted[j - 1]; sorted[j - 1] = t; }
@@ -674,13 +717,15 @@ int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const Bhw
         const uint64_t nxt = (i + 1 < nb) ? sorted[i + 1] : (uint64_t)sorted[0] + E;
         if (nxt - sorted[i] > maxgap) maxgap = nxt - sorted[i];
     }
-    tp.n_tiles = (uint32_t)((maxgap + kTileThreads - 1) / kTileThreads);
-    const bool acc32 = (w.combine == BHW_COMBINE_HLS) || (c.dat_width + 2 <= 32);
+    const uint32_t lanes = (nb >= 15) ? (uint32_t)kTileLanes : (uint32_t)kTileThreads;
+    tp.n_tiles = (uint32_t)((maxgap + lanes - 1) / lanes);
+    const int mode = (w.combine != BHW_COMBINE_HLS) ? 2 : (c.ones_neg ? 1 : 0);
     const dim3 grid(tp.n_tiles), block(kTileThreads);
 #define BHW_LAUNCH_TILE(NB)                                                                                              \
     do {                                                                                                                 \
-        if (acc32) hipLaunchKernelGGL((k_table_combine_tile<NB, int32_t>), grid, block, 0, st, c, w, tp, (const int2 *)d_table, d_out); \
-        else       hipLaunchKernelGGL((k_table_combine_tile<NB, int64_t>), grid, block, 0, st, c, w, tp, (const int2 *)d_table, d_out); \
+        if (mode == 0)      hipLaunchKernelGGL((k_table_combine_tile<NB, 0>), grid, block, 0, st, c, w, tp, (const int2 *)d_table, d_out); \
+        else if (mode == 1) hipLaunchKernelGGL((k_table_combine_tile<NB, 1>), grid, block, 0, st, c, w, tp, (const int2 *)d_table, d_out); \
+        else                hipLaunchKernelGGL((k_table_combine_tile<NB, 2>), grid, block, 0, st, c, w, tp, (const int2 *)d_table, d_out); \
     } while (0)
     if (nb == 15) BHW_LAUNCH_TILE(15);
     else if (nb == 3) BHW_LAUNCH_TILE(3);
