@@ -1,0 +1,56 @@
+"""The C++ host mirror (include/bhw.hpp) re-hosting the reference's own host programs on the C ABI:
+its text outputs must equal the reference's files byte for byte."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "blackman_harris_win_amd")
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("cpp") / "host_mirror")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "host_mirror.cpp"), "-o", out,
+                    "-L" + PKG, "-lbhw", "-Wl,-rpath," + PKG], check=True)
+    return out
+
+
+def test_cpp_host_compiles_and_reports_errors_without_gpu(exe):
+    """No GPU needed: parameter errors surface as bhw::error with the ABI's codes."""
+    import torch
+    r = subprocess.run([exe], capture_output=True)
+    assert r.returncode == 64
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, "coe", "14", "12"], capture_output=True)
+        assert r.returncode == 2 and b"no CPU path" in r.stderr     # fails loudly, no fallback
+
+
+@pytest.mark.gpu
+def test_coe_dat_byte_identical_to_reference(exe, golden):
+    r = subprocess.run([exe, "coe", "14", "12"], capture_output=True, check=True)
+    assert hashlib.md5(r.stdout).hexdigest() == golden["coe_cpp_14_12"]["text_md5"] == "b65f091fb2afeeb252aa0bc5728fe46a"
+
+
+@pytest.mark.gpu
+def test_dout_dat_matches_oracle_text(exe):
+    r = subprocess.run([exe, "dout", "5", "10", "24"], capture_output=True, check=True)
+    want = "".join("%d \n" % v for v in O.generate(O.oparams(5, 10, 24), 0, 1024)).encode()
+    assert r.stdout == want
+
+
+@pytest.mark.gpu
+def test_streaming_bursts_and_errors(exe):
+    r = subprocess.run([exe, "stream"], capture_output=True, check=True)
+    total = int(r.stderr.split()[-1])
+    full = O.generate(O.oparams(5, 10, 24), 0, 1024)
+    want = np.tile(full, 4)[:total]
+    got = np.array([int(x) for x in r.stdout.split()], dtype=np.int32)
+    assert np.array_equal(got, want)
+    assert subprocess.run([exe, "errors"], capture_output=True).returncode == 0

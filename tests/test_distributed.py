@@ -1,0 +1,76 @@
+"""The N>1 path on CPU (gloo, world_size 2): bench.py's shard plan, barrier/max-over-ranks protocol and the
+index-range sharding of the selector, with the oracle standing in for the GPU step."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import time
+    import torch
+    import torch.distributed as dist
+    import bench
+    import oracle_lib as O
+    from blackman_harris_win_amd import shard_range
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    # (1) strong-scaling shard of one window (SURVEY 8e / config C5 at small size): contiguous, no collective
+    p = O.oparams(7, 12, 32)
+    n0, count = shard_range(1 << 12, rank, world)
+    shard = O.generate(p, n0, count)
+    np.save(os.path.join(outdir, f"shard{rank}.npy"), shard)
+    # (2) bench.py's weak-scaling plan: rank r owns stream indices [r*2^26, (r+1)*2^26)
+    b0, bc = bench.shard_for(rank)
+    assert (b0, bc) == (rank << 26, 1 << 26)
+    # (3) the timing protocol: barrier + sync brackets, MAX over ranks
+    calls = {"n": 0}
+
+    def step():
+        calls["n"] += 1
+        time.sleep(0.01 * (rank + 1))          # rank 1 is slower: the reported time must be its time
+
+    def allreduce_max(v):
+        t = torch.tensor([v], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    elapsed = bench.timed_steps(step, steps=5, warmup=2, barrier=dist.barrier, sync=lambda: None, allreduce_max=allreduce_max)
+    assert calls["n"] == 7
+    assert elapsed >= 5 * 0.01 * world * 0.9
+    gathered = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(gathered, torch.tensor([elapsed], dtype=torch.float64))
+    assert all(abs(float(g) - elapsed) < 1e-12 for g in gathered)      # every rank reports the same max
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    whole = O.generate(O.oparams(7, 12, 32), 0, 1 << 12)
+    got = np.concatenate([np.load(tmp_path / "shard0.npy"), np.load(tmp_path / "shard1.npy")])
+    assert np.array_equal(got, whole)
+
+
+def test_bench_refuses_mismatched_world(monkeypatch):
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, env=env)
+    assert r.returncode != 0 and b"WORLD_SIZE" in r.stderr
