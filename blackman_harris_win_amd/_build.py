@@ -47,8 +47,9 @@ def build_library(force=False, verbose=False):
     rom_o = os.path.join(CSRC, "bhw_rom.o")
     _run(["gcc", "-O2", "-fPIC", "-c", os.path.join(CSRC, "bhw_rom.c"), "-o", rom_o])
     quad = subprocess.run(["gcc", "-print-file-name=libquadmath.so"], stdout=subprocess.PIPE, text=True).stdout.strip()
+    extra = os.environ.get("BHW_EXTRA_FLAGS", "").split()
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", "-x", "hip",
+           "-Wno-unused-function"] + extra + ["-x", "hip",
            os.path.join(CSRC, "bhw_api.cpp"), os.path.join(CSRC, "bhw_kernels.hip"),
            "-x", "none", rom_o, quad, "-Wl,-rpath," + os.path.dirname(os.path.realpath(quad)),
            "-o", LIB]

@@ -354,8 +354,25 @@ __global__ __launch_bounds__(kBlock) void k_table_combine_fold(BhwCordicCfg cfg,
 // The 15 run offsets are ~E/15 apart, so tiles m = 0..n_tiles-1 cover the ring once; the few entries
 // covered twice at the seams are recomputed with identical results (idempotent stores).
 // ---------------------------------------------------------------------------------------
-constexpr int kTileThreads = 256;
-constexpr int kTileLanes = 256;     // tile width; with kTileLanes < kTileThreads the runs are split over thread groups (measured slower)
+#ifdef BHW_NT_LOAD
+__device__ __forceinline__ int2 bhw_nt_load(const int2 *p)
+{
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    const v2i v = __builtin_nontemporal_load(reinterpret_cast<const v2i *>(p));
+    return make_int2(v.x, v.y);
+}
+#define BHW_TABLE_LOAD(p) bhw_nt_load(p)
+#else
+#define BHW_TABLE_LOAD(p) (*(p))
+#endif
+#ifndef BHW_TILE_THREADS
+#define BHW_TILE_THREADS 768
+#endif
+#ifndef BHW_TILE_LANES
+#define BHW_TILE_LANES 256
+#endif
+constexpr int kTileThreads = BHW_TILE_THREADS;
+constexpr int kTileLanes = BHW_TILE_LANES;     // tile width in lanes; the tile's 15 runs are split over kTileThreads / kTileLanes thread groups
 
 struct BhwTilePlan {
     uint32_t offs[16];   // (i3*inv3 + i5*inv5) mod ring, index i3 + 3*i5; padded by repeating the last run
@@ -437,7 +454,7 @@ __global__ __launch_bounds__(kTileThreads) void k_table_combine_tile(BhwCordicCf
             const uint32_t r = (rbase + offs[b]) & hmask;                                             \
             _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                             \
                 const uint32_t theta = ((uint32_t)K * (r + (uint32_t)g * H)) & mask;                     \
-                cs[b][g] = table[tab_index(theta & emask, lq, 1u)];                                      \
+                cs[b][g] = BHW_TABLE_LOAD(&table[tab_index(theta & emask, lq, 1u)]);                     \
             }                                                                                            \
         }                                                                                                \
         _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
@@ -466,7 +483,11 @@ __global__ __launch_bounds__(kTileThreads) void k_table_combine_tile(BhwCordicCf
                 int32_t v;
                 if constexpr (MODE == 2) v = combine_final((int64_t)acc[b][h][j], W, win.combine, win.n_terms);
                 else v = (int32_t)((uint32_t)acc[b][h][j] << (32u - W)) >> (32u - W);   // (win_t)(...) wrap to W bits
+#ifdef BHW_NT_STORE
+                __builtin_nontemporal_store(v, &out[r + (uint32_t)h * H + (uint32_t)j * E]);
+#else
                 out[r + (uint32_t)h * H + (uint32_t)j * E] = v;
+#endif
             }
     }
 }
@@ -727,7 +748,12 @@ int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const Bhw
         else if (mode == 1) hipLaunchKernelGGL((k_table_combine_tile<NB, 1>), grid, block, 0, st, c, w, tp, (const int2 *)d_table, d_out); \
         else                hipLaunchKernelGGL((k_table_combine_tile<NB, 2>), grid, block, 0, st, c, w, tp, (const int2 *)d_table, d_out); \
     } while (0)
-    if (nb == 15) BHW_LAUNCH_TILE(15);
+    if (nb == 15) {
+        // 64-bit sums for 15 runs do not fit the register file: bhwk_tile_applicable() routes that case to the fold kernel
+        if (mode == 2) return (int)hipErrorInvalidValue;
+        if (mode == 0) hipLaunchKernelGGL((k_table_combine_tile<15, 0>), grid, block, 0, st, c, w, tp, (const int2 *)d_table, d_out);
+        else           hipLaunchKernelGGL((k_table_combine_tile<15, 1>), grid, block, 0, st, c, w, tp, (const int2 *)d_table, d_out);
+    }
     else if (nb == 3) BHW_LAUNCH_TILE(3);
     else BHW_LAUNCH_TILE(1);
 #undef BHW_LAUNCH_TILE
