@@ -88,6 +88,17 @@ def cpu_baseline(target_seconds=12.0, max_threads=16):
             "matches_oracle": ok}
 
 
+def pmc_traffic():
+    """HBM bytes per step from the committed rocprofv3 PMC passes of this same command (tools/gpu_pmc.sh ->
+    profiles/pmc_latest.json): 2 x FETCH_SIZE + WRITE_SIZE per kernel, summed over the kernels of one step (the gfx950
+    correction of MI355X_MICROARCH.md section HBM; WRITE_SIZE calibrated on the build kernel's known 8 B x 2^24)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            return float(json.load(f)["_step_hbm_bytes"])
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,9 +189,13 @@ def main():
                    "phi_width": PHI_WIDTH, "dat_width": DAT_WIDTH, "n_terms": 7, "coefficients_per_step_per_gpu": count,
                    "strategy": args.algo, "sharding": "contiguous stream-index range per rank, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic() if args.algo in ("auto", "table") else None,
                      "device_ms_per_step": dev_ms,
-                     "note": "achieved = 4 B x 2^26 coefficients / device time of one step (all kernels of the step, HIP events on the launch stream)"},
+                     "algorithmic_bytes": BYTES_PER_COEFF * count,
+                     "note": "achieved = 4 B x 2^26 coefficients / device time of one step (both kernels of the step: table build + "
+                             "tile combine; HIP events on the launch stream); traffic = HBM bytes per step from PMC (profiles/), "
+                             "above the algorithmic bytes because the strategy round-trips a 128 MiB (c,s) table"},
         "parity_spot_check": parity,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

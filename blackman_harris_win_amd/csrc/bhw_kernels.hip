@@ -280,6 +280,39 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Direct kernel, fast form: one lane per coefficient, K-1 full CORDIC chains per lane in the same
+// 8-instruction rotation step as the table build (no sharing between lanes), rescaled ROM staged in LDS
+// and read with immediate offsets, one coalesced int32 store per lane.
+// ---------------------------------------------------------------------------------------
+template <int NITER>
+__global__ __launch_bounds__(kBlock) void k_direct_fast(BhwCordicCfg cfg, BhwWinCfg win, uint64_t n0, uint64_t count,
+                                                         int32_t *__restrict__ out)
+{
+    __shared__ uint32_t lut_s[32];
+    if (threadIdx.x < 32) lut_s[threadIdx.x] = (uint32_t)cfg.lut[threadIdx.x];
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t pw = cfg.phi_width;
+    const uint32_t mask = (pw >= 32) ? 0xFFFFFFFFu : ((1u << pw) - 1u);
+    const uint32_t tmask = (1u << (pw - 2)) - 1u;
+    const uint32_t n = (uint32_t)(n0 + i) & mask;
+    int64_t acc = win.aa[0];
+    for (uint32_t k = 1; k < win.n_terms; ++k) {
+        const uint32_t theta = (k * n) & mask;
+        const uint32_t u = (theta & tmask) >> cfg.z_shr;
+        int64_t x = cfg.x0, y = cfg.x0;                                          // rotation 0 always adds (z0 >= 0)
+        int32_t z = (int32_t)((u << cfg.z_shl) - lut_s[0]);
+#pragma unroll
+        for (int r = 1; r < NITER; ++r) rot_step(x, y, z, r, lut_s[r]);
+        int32_t c, s;
+        quadrant_map(theta >> (pw - 2), (int32_t)(x >> cfg.out_shr), (int32_t)(y >> cfg.out_shr), cfg.ones_neg, c, s);
+        combine_term(acc, win.aa[k], c, k, cfg.dat_width, win.combine);
+    }
+    out[i] = combine_final(acc, cfg.dat_width, win.combine, win.n_terms);
+}
+
 // Table strategy, pass 2 (general form): one lane per coefficient, K-1 gathers.
 __global__ __launch_bounds__(kBlock) void k_table_combine(BhwCordicCfg cfg, BhwWinCfg win, const int2 *__restrict__ table,
                                                            uint64_t n0, uint64_t count, int32_t *__restrict__ out)
@@ -611,6 +644,19 @@ int bhwk_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, u
     if (!count) return 0;
     BHW_SET_DEVICE(l);
     hipStream_t st = (hipStream_t)l.stream;
+    if (c.dat_width + c.out_shr <= 34 && c.n_iter >= 7) {   // |x| < 2^33, quarter circle <= 2^32: the mad-form rotation applies
+        const dim3 grid(grid_for(count)), block(kBlock);
+        switch (c.n_iter) {
+#define BHW_CASE(N) case N: hipLaunchKernelGGL(k_direct_fast<N>, grid, block, 0, st, c, w, n0, count, d_out); break;
+            BHW_CASE(7) BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14)
+            BHW_CASE(15) BHW_CASE(16) BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20) BHW_CASE(21) BHW_CASE(22)
+            BHW_CASE(23) BHW_CASE(24) BHW_CASE(25) BHW_CASE(26) BHW_CASE(27) BHW_CASE(28) BHW_CASE(29) BHW_CASE(30)
+            BHW_CASE(31) BHW_CASE(32)
+#undef BHW_CASE
+        default: return (int)hipErrorInvalidValue;
+        }
+        return finish(hipSuccess);
+    }
     if (c.wide) hipLaunchKernelGGL(k_direct<int64_t>, dim3(grid_for(count)), dim3(kBlock), 0, st, c, w, n0, count, d_out);
     else        hipLaunchKernelGGL(k_direct<int32_t>, dim3(grid_for(count)), dim3(kBlock), 0, st, c, w, n0, count, d_out);
     return finish(hipSuccess);

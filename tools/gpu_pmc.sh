@@ -16,8 +16,24 @@ agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_${tag}_*/*/*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
         agg[row["Kernel_Name"][:48]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+import json
+summary={}
 for k,v in agg.items():
     print(k)
+    summary[k]={}
     for c,vals in sorted(v.items()):
         print("   %-24s n=%3d  mean=%.4g" % (c,len(vals),sum(vals)/len(vals)))
+        summary[k][c]={"launches":len(vals),"mean":sum(vals)/len(vals)}
+# HBM traffic per launch, MI355X_MICROARCH.md section HBM: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts
+# 128-B requests as 64 B -> doubled (cross-checked against TCC_EA0_RDREQ_sum x 128 B); WRITE_SIZE is exact (calibrated
+# on the table-build kernel, which writes exactly 8 B x entries).
+step=0.0
+for k,v in summary.items():
+    if "rocclr" in k: continue
+    f=2*1024*v.get("FETCH_SIZE",{}).get("mean",0.0); w=1024*v.get("WRITE_SIZE",{}).get("mean",0.0)
+    v["hbm_bytes_per_launch"]={"read":f,"write":w,"total":f+w}
+    step+=f+w
+summary["_step_hbm_bytes"]=step
+json.dump(summary,open("gpurun_out/pmc_summary_${tag}.json","w"),indent=1,sort_keys=True)
+print("step HBM bytes: %.1f MB" % (step/1e6))
 PY
