@@ -150,34 +150,36 @@ void resolve_window(const bhw_params *p, BhwWinCfg &w)
     w.combine = p->combine;
 }
 
-// ---- per-device library-owned scratch ---------------------------------------------------------
+// ---- library-owned scratch, one buffer per (device, stream) ------------------------------------
+// Calls on different streams may run concurrently, so they must not share a table buffer; calls on one
+// stream are ordered by the stream.  Callers that want no allocation in the launch path (graph capture)
+// pass their own workspace through bhw_exec instead.
 struct DeviceScratch {
-    void *buf = nullptr;
-    uint64_t bytes = 0;
+    std::map<void *, std::pair<void *, uint64_t>> bufs;   // stream -> (buffer, bytes)
     // Taylor ROM cache keyed by (W, L)
     std::map<std::pair<uint32_t, uint32_t>, int32_t *> roms;
 };
 std::mutex g_mu;
 std::map<int, DeviceScratch> g_scratch;
 
-int ensure_scratch(int device, uint64_t bytes, void **out)
+int ensure_scratch(int device, void *stream, uint64_t bytes, void **out)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    DeviceScratch &s = g_scratch[device];
-    if (s.bytes < bytes) {
+    auto &slot = g_scratch[device].bufs[stream];
+    if (slot.second < bytes) {
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
-        if (s.buf) {
-            (void)hipDeviceSynchronize();
-            (void)hipFree(s.buf);
-            s.buf = nullptr;
-            s.bytes = 0;
+        if (slot.first) {
+            (void)hipStreamSynchronize((hipStream_t)stream);   // earlier launches on this stream may still read it
+            (void)hipFree(slot.first);
+            slot = {nullptr, 0};
         }
-        e = hipMalloc(&s.buf, bytes);
+        void *b = nullptr;
+        e = hipMalloc(&b, bytes);
         if (e != hipSuccess) return fail_hip(e, "hipMalloc(scratch)");
-        s.bytes = bytes;
+        slot = {b, bytes};
     }
-    *out = s.buf;
+    *out = slot.first;
     return BHW_OK;
 }
 
@@ -269,7 +271,7 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
                         (unsigned long long)need);
         ws = ex->workspace;
     } else {
-        rc = ensure_scratch(device, need, &ws);
+        rc = ensure_scratch(device, stream, need, &ws);
         if (rc) return rc;
     }
     const uint64_t N = 1ull << p->phi_width;
@@ -478,7 +480,8 @@ int bhw_release_device(int device)
     if (it == g_scratch.end()) return BHW_OK;
     if (hipSetDevice(device) == hipSuccess) {
         (void)hipDeviceSynchronize();
-        if (it->second.buf) (void)hipFree(it->second.buf);
+        for (auto &kv : it->second.bufs)
+            if (kv.second.first) (void)hipFree(kv.second.first);
         for (auto &kv : it->second.roms) (void)hipFree(kv.second);
     }
     g_scratch.erase(it);

@@ -313,6 +313,30 @@ __global__ __launch_bounds__(kBlock) void k_direct_fast(BhwCordicCfg cfg, BhwWin
     out[i] = combine_final(acc, cfg.dat_width, win.combine, win.n_terms);
 }
 
+// sin/cos sweep, fast form (cordic() alone in the mad-form rotation).
+template <int NITER>
+__global__ __launch_bounds__(kBlock) void k_sincos_fast(BhwCordicCfg cfg, uint64_t theta0, uint64_t count,
+                                                         int32_t *__restrict__ d_sin, int32_t *__restrict__ d_cos)
+{
+    __shared__ uint32_t lut_s[32];
+    if (threadIdx.x < 32) lut_s[threadIdx.x] = (uint32_t)cfg.lut[threadIdx.x];
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t pw = cfg.phi_width;
+    const uint32_t mask = (pw >= 32) ? 0xFFFFFFFFu : ((1u << pw) - 1u);
+    const uint32_t theta = (uint32_t)(theta0 + i) & mask;
+    const uint32_t u = (theta & ((1u << (pw - 2)) - 1u)) >> cfg.z_shr;
+    int64_t x = cfg.x0, y = cfg.x0;
+    int32_t z = (int32_t)((u << cfg.z_shl) - lut_s[0]);
+#pragma unroll
+    for (int r = 1; r < NITER; ++r) rot_step(x, y, z, r, lut_s[r]);
+    int32_t c, s;
+    quadrant_map(theta >> (pw - 2), (int32_t)(x >> cfg.out_shr), (int32_t)(y >> cfg.out_shr), cfg.ones_neg, c, s);
+    if (d_sin) d_sin[i] = s;
+    if (d_cos) d_cos[i] = c;
+}
+
 // Table strategy, pass 2 (general form): one lane per coefficient, K-1 gathers.
 __global__ __launch_bounds__(kBlock) void k_table_combine(BhwCordicCfg cfg, BhwWinCfg win, const int2 *__restrict__ table,
                                                            uint64_t n0, uint64_t count, int32_t *__restrict__ out)
@@ -667,6 +691,19 @@ int bhwk_sincos(const BhwLaunch &l, const BhwCordicCfg &c, uint64_t theta0, uint
     if (!count) return 0;
     BHW_SET_DEVICE(l);
     hipStream_t st = (hipStream_t)l.stream;
+    if (c.dat_width + c.out_shr <= 34 && c.n_iter >= 7) {
+        const dim3 grid(grid_for(count)), block(kBlock);
+        switch (c.n_iter) {
+#define BHW_CASE(N) case N: hipLaunchKernelGGL(k_sincos_fast<N>, grid, block, 0, st, c, theta0, count, d_sin, d_cos); break;
+            BHW_CASE(7) BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14)
+            BHW_CASE(15) BHW_CASE(16) BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20) BHW_CASE(21) BHW_CASE(22)
+            BHW_CASE(23) BHW_CASE(24) BHW_CASE(25) BHW_CASE(26) BHW_CASE(27) BHW_CASE(28) BHW_CASE(29) BHW_CASE(30)
+            BHW_CASE(31) BHW_CASE(32)
+#undef BHW_CASE
+        default: return (int)hipErrorInvalidValue;
+        }
+        return finish(hipSuccess);
+    }
     if (c.wide) hipLaunchKernelGGL(k_sincos<int64_t>, dim3(grid_for(count)), dim3(kBlock), 0, st, c, theta0, count, d_sin, d_cos);
     else        hipLaunchKernelGGL(k_sincos<int32_t>, dim3(grid_for(count)), dim3(kBlock), 0, st, c, theta0, count, d_sin, d_cos);
     return finish(hipSuccess);
@@ -772,7 +809,11 @@ int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const Bhw
     for (int i5 = 0; i5 < nb5; ++i5)
         for (int i3 = 0; i3 < nb3; ++i3) {
             const uint32_t o = (uint32_t)(((uint64_t)i3 * inv3 + (uint64_t)i5 * inv5) & (E - 1u));
-            tp.offs[i3 + nb3 * i5] = o;
+#ifdef BHW_RUNS_BY_I5
+            tp.offs[i3 + nb3 * i5] = o;      // thread group = consecutive (i3, i5) pairs
+#else
+            tp.offs[i5 + nb5 * i3] = o;      // thread group p holds the five inv5-siblings of i3 = p: k = 5 is dense per thread
+#endif
             sorted[i3 + nb3 * i5] = o;
         }
     for (int i = nb; i < 16; ++i) tp.offs[i] = tp.offs[nb - 1];

@@ -189,6 +189,22 @@ def test_explicit_workspace_and_stream(torch):
     assert ei.value.code == -4
 
 
+def test_concurrent_streams_use_separate_library_scratch(torch):
+    """Two different windows generated concurrently on two streams with library-owned scratch must not share a table."""
+    import blackman_harris_win_amd as bhw
+    pa, pb = B.make_params(7, 18, 32), B.make_params(5, 18, 24, model=B.MODEL_CPP)
+    wa, wb = O.generate(O.from_bhw(pa), 0, 1 << 18), O.generate(O.from_bhw(pb), 0, 1 << 18)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(4):
+        with torch.cuda.stream(sa):
+            ga = bhw.generate(pa, 0, 1 << 18, algo=B.ALGO_TABLE)
+        with torch.cuda.stream(sb):
+            gb = bhw.generate(pb, 0, 1 << 18, algo=B.ALGO_TABLE)
+        torch.cuda.synchronize()
+        assert np.array_equal(ga.cpu().numpy(), wa) and np.array_equal(gb.cpu().numpy(), wb)
+    assert B.lib().bhw_release_device(0) == 0
+
+
 # ---- the selector / HLS-top mirrors -------------------------------------------------------------------
 def test_win_selector_streaming_counter(torch):
     from blackman_harris_win_amd import WinSelector

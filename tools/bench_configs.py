@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Timings of the other BASELINE.json configs on one GPU (informative; the contract line is bench.py).
+C2: BH-4 N=2^20 24-bit; C3: BH-7 N=2^26 32-bit (both strategies); C4: 1024 x BH-4 N=2^16 24-bit, replicate vs recompute;
+C5 shard: BH-7 26/32, one 2^23 shard; sincos sweep 2^26 (model CPP)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import blackman_harris_win_amd as bhw  # noqa: E402
+from blackman_harris_win_amd import binding as B  # noqa: E402
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    res = {}
+    p2 = bhw.make_params(4, 20, 24)
+    o2 = torch.empty(1 << 20, dtype=torch.int32, device="cuda")
+    for name, algo in (("direct", B.ALGO_DIRECT), ("table", B.ALGO_TABLE)):
+        ms = timeit(lambda: bhw.generate(p2, 0, 1 << 20, out=o2, algo=algo))
+        res[f"C2_bh4_2^20_24bit_{name}"] = {"ms": ms, "Gsamples/s": (1 << 20) / ms / 1e6}
+    p3 = bhw.make_params(7, 26, 32)
+    o3 = torch.empty(1 << 26, dtype=torch.int32, device="cuda")
+    for name, algo, it in (("direct", B.ALGO_DIRECT, 3), ("table", B.ALGO_TABLE, 20)):
+        ms = timeit(lambda: bhw.generate(p3, 0, 1 << 26, out=o3, algo=algo), iters=it, warm=1)
+        res[f"C3_bh7_2^26_32bit_{name}"] = {"ms": ms, "Gsamples/s": (1 << 26) / ms / 1e6}
+    for name, algo in (("direct", B.ALGO_DIRECT), ("table", B.ALGO_TABLE)):
+        ms = timeit(lambda: bhw.generate(p3, 3 << 23, 1 << 23, out=o3, algo=algo), iters=5, warm=1)
+        res[f"C5_shard_2^23_of_2^26_{name}"] = {"ms": ms, "Gsamples/s": (1 << 23) / ms / 1e6}
+    p4 = bhw.make_params(4, 16, 24)
+    o4 = torch.empty((1024, 1 << 16), dtype=torch.int32, device="cuda")
+    ms = timeit(lambda: bhw.generate_batched(p4, 1024, out=o4))
+    res["C4_1024x_bh4_2^16_replicate"] = {"ms": ms, "Gsamples/s": (1 << 26) / ms / 1e6, "GB/s": 4 * (1 << 26) / ms / 1e6}
+    ms = timeit(lambda: bhw.generate(p4, 0, 1 << 26, out=o4.view(-1), algo=B.ALGO_DIRECT), iters=3, warm=1)
+    res["C4_1024x_bh4_2^16_recompute_direct"] = {"ms": ms, "Gsamples/s": (1 << 26) / ms / 1e6}
+    pc = bhw.make_params(1, 26, 32, model=B.MODEL_CPP)
+    ms = timeit(lambda: bhw.cordic(pc, 0, 1 << 26), iters=5, warm=1)
+    res["sincos_cpp_2^26_32bit"] = {"ms": ms, "Gphases/s": (1 << 26) / ms / 1e6}
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
