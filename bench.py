@@ -168,14 +168,22 @@ def main():
     dev_ms = ev0.elapsed_time(ev1) / args.steps
     dev_ms = allreduce_max(dev_ms)
 
-    # parity spot-check outside the timed region (the full check is tests/test_gpu_parity.py)
-    import numpy as np
-    import oracle_lib as O
-    po = O.from_bhw(params)
-    idx = [0, 1, 12345, COUNT // 4, COUNT // 2, COUNT - 1]
-    parity = all(int(out[i]) == int(O.generate(po, n0 + i, 1)[0]) for i in idx)
-    head = np.array_equal(out[:4096].cpu().numpy(), O.generate(po, n0, 4096))
-    parity = bool(parity and head)
+    # parity check outside the timed region, against the committed golden fixture of this exact config
+    # (tests/golden/golden.json, C3: sparse samples, per-shard sums and 8 x 1024 strided samples); the full
+    # bit-for-bit comparison with the oracle is tests/test_gpu_parity.py
+    parity = None
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
+            g = json.load(f)["entries"]["C3_bh7_26_32"]
+        parity = all(int(out[int(n)]) == v for n, v in g["sparse"].items())
+        step_s = (1 << 23) // 1024
+        for sh, e in enumerate(g["shards"]):
+            seg = out[sh << 23:(sh + 1) << 23]
+            parity = parity and int(seg.sum(dtype=torch.int64)) == e["sum"]
+            parity = parity and seg[::step_s][:1024].cpu().tolist() == e["strided_1024"]
+        parity = bool(parity)
+    except FileNotFoundError:
+        pass
 
     total = world * args.steps * count
     value = total / elapsed / 1e9

@@ -503,9 +503,15 @@ __global__ __launch_bounds__(kTileThreads) void k_table_combine_tile(BhwCordicCf
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[b][h][j] = (acc_t)win.aa[0];
 
+#ifdef BHW_TILE_SYNC
+#define BHW_TILE_ALIGN() if (kParts > 1) __syncthreads()
+#else
+#define BHW_TILE_ALIGN()
+#endif
 #define BHW_TILE_HARMONIC(K)                                                                             \
     if (win.n_terms > K) {                                                                               \
         constexpr int NG = (K & 1) ? 2 : 1;                                                              \
+        BHW_TILE_ALIGN();   /* keep the thread groups in step so sibling runs hit the same lines together */ \
         int2 cs[NR][NG];                                                                                 \
         _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
             const uint32_t r = (rbase + offs[b]) & hmask;                                             \

@@ -149,6 +149,32 @@ def test_whole_period_tile_path(torch, win, pw, w, model, combine):
     assert np.array_equal(two[:n], want) and np.array_equal(two[n:], want)
 
 
+def test_strategies_agree_on_random_whole_windows(torch):
+    """Size-independent property: DIRECT (one CORDIC chain per harmonic per coefficient) and TABLE (shared table,
+    folds, gather tiles) are different computations of the same integers -- whole windows must be identical."""
+    import blackman_harris_win_amd as bhw
+    rng = np.random.default_rng(2024)
+    for _ in range(24):
+        win = int(rng.choice([1, 2, 3, 4, 5, 7]))
+        model = int(rng.integers(0, 3))
+        combine = int(rng.integers(0, 2))
+        w = int(rng.integers(8, 33))
+        pw = int(rng.integers(14, 23))
+        if model == B.MODEL_HLS and pw > w + 2:
+            pw = w + 2
+        prec = int(rng.integers(1, 3)) if model == B.MODEL_VHDL else 1
+        aa = [int(v) for v in rng.integers(-(1 << (w - 1)), 1 << (w - 1), 7)] if rng.random() < 0.5 else None
+        p = B.make_params(win, pw, w, model=model, combine=combine, precision=prec, aa=aa)
+        a = bhw.generate(p, 0, 1 << pw, algo=B.ALGO_DIRECT)
+        b = bhw.generate(p, 0, 1 << pw, algo=B.ALGO_TABLE)
+        assert bool((a == b).all()), (win, model, combine, w, pw, prec, aa)
+        # and an unaligned slice through the general (non-fold) table path
+        n0, cnt = int(rng.integers(1, 1 << pw)), int(rng.integers(1, 5000))
+        c = bhw.generate(p, n0, cnt, algo=B.ALGO_TABLE)
+        ref = torch.cat([a, a, a])[n0:n0 + cnt] if n0 + cnt <= 3 << pw else None
+        assert ref is None or bool((c == ref).all()), (win, model, combine, w, pw, n0, cnt)
+
+
 # ---- edge cases: empty, ragged, offsets, wrap-around --------------------------------------------------------
 @pytest.mark.parametrize("algo", ALGOS)
 def test_ragged_counts_and_offsets(torch, algo):
