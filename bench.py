@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for the barrier / max-over-ranks (nccl = RCCL; gloo only to rehearse N>1 "
+                         "on a box with fewer GPUs than ranks, together with BHW_BENCH_SHARE_GPU=1)")
     args = ap.parse_args()
 
     import torch
@@ -121,13 +124,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the generator has no CPU path)")
+    if os.environ.get("BHW_BENCH_SHARE_GPU") == "1":        # rehearsal only: all ranks on one GPU
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm; used for barrier/max only
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm; used for barrier/max only
+        else:
+            dist.init_process_group(backend="gloo")
 
     algo = {"auto": B.ALGO_AUTO, "direct": B.ALGO_DIRECT, "table": B.ALGO_TABLE}[args.algo]
     params = bhw.make_params(WIN, PHI_WIDTH, DAT_WIDTH)          # model HLS + HLS combine + built-in a_k
@@ -146,7 +154,7 @@ def main():
     def allreduce_max(v):
         if dist is None:
             return v
-        t = torch.tensor([v], dtype=torch.float64, device=dev)
+        t = torch.tensor([v], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
