@@ -158,9 +158,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    # device-side duration of the K steps on the launch stream (HIP events), for the roofline figure
+    # device-side duration of the K timed steps on the launch stream (HIP events), for the roofline figure
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     state = {"n": 0}
+    table_algo = ws_bytes > 0
 
     def step_with_events():
         if state["n"] == 0:
@@ -175,6 +176,28 @@ def main():
     elapsed = timed_steps(step_with_events, args.steps, 0, barrier, torch.cuda.synchronize, allreduce_max)
     dev_ms = ev0.elapsed_time(ev1) / args.steps
     dev_ms = allreduce_max(dev_ms)
+
+    # per-kernel split, outside the timed region: a few extra steps with the library's event recorded between
+    # the table build and the combine pass (cross-check for the rocprofv3 kernel stats under profiles/)
+    per_kernel = None
+    if table_algo:
+        reps = min(10, args.steps)
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(reps)]
+        for trio in evs:
+            for e in trio:
+                e.record()                 # creates the handles; re-recorded below
+        torch.cuda.synchronize()
+        for e0, em, e1 in evs:
+            e0.record()
+            bhw.generate(params, n0, count, out=out, algo=algo, workspace=workspace, event_after_build=em)
+            e1.record()
+        torch.cuda.synchronize()
+        build_us = sum(t[0].elapsed_time(t[1]) for t in evs) / reps * 1e3
+        comb_us = sum(t[1].elapsed_time(t[2]) for t in evs) / reps * 1e3
+        per_kernel = {"k_table_build_shared": {"avg_us": build_us},
+                      "k_table_combine_tile": {"avg_us": comb_us, "dominant": True,
+                                               "achieved_alone_GBps": BYTES_PER_COEFF * count / (comb_us * 1e-6) / 1e9},
+                      "note": "event-to-event, includes the launch gap; rocprofv3 kernel stats under profiles/"}
 
     # parity check outside the timed region, against the committed golden fixture of this exact config
     # (tests/golden/golden.json, C3: sparse samples, per-shard sums and 8 x 1024 strided samples); the full
@@ -208,7 +231,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic() if args.algo in ("auto", "table") else None,
                      "device_ms_per_step": dev_ms,
-                     "algorithmic_bytes": BYTES_PER_COEFF * count,
+                     "algorithmic_bytes": BYTES_PER_COEFF * count, "per_kernel": per_kernel,
                      "note": "achieved = 4 B x 2^26 coefficients / device time of one step (both kernels of the step: table build + "
                              "tile combine; HIP events on the launch stream); traffic = HBM bytes per step from PMC (profiles/), "
                              "above the algorithmic bytes because the strategy round-trips a 128 MiB (c,s) table"},

@@ -38,7 +38,8 @@ class BhwParams(ctypes.Structure):
 
 class BhwExec(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("algo", ctypes.c_uint32),
-                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_uint64)]
+                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_uint64),
+                ("event_after_build", ctypes.c_void_p)]
 
 
 _lib = None

@@ -280,6 +280,10 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
     c.tab_split = tiled ? 1u : 0u;
     int e = bhwk_table_build(l, c, (int32_t *)ws);
     if (e) return fail_hip(e, "table build launch");
+    if (ex && ex->event_after_build) {
+        hipError_t he = hipEventRecord((hipEvent_t)ex->event_after_build, (hipStream_t)stream);
+        if (he != hipSuccess) return fail_hip(he, "hipEventRecord(event_after_build)");
+    }
     if (whole) {
         // whole periods: quadrant-fold combine for the first, store-only replication for the rest
         e = tiled ? bhwk_table_combine_tile(l, c, w, (const int32_t *)ws, d_out)

@@ -40,7 +40,7 @@ def shard_range(total, rank, world_size):
     return n0, base + (1 if rank < rem else 0)
 
 
-def generate(params, n0, count, *, device=None, out=None, algo=B.ALGO_AUTO, workspace=None):
+def generate(params, n0, count, *, device=None, out=None, algo=B.ALGO_AUTO, workspace=None, event_after_build=None):
     """count coefficients starting at stream index n0 as an int32 CUDA tensor (bhw_generate_device)."""
     torch = _torch()
     dev = _dev_index(torch, device)
@@ -56,6 +56,8 @@ def generate(params, n0, count, *, device=None, out=None, algo=B.ALGO_AUTO, work
     if workspace is not None:
         ex.workspace = workspace.data_ptr()
         ex.workspace_bytes = workspace.numel() * workspace.element_size()
+    if event_after_build is not None:      # a torch.cuda.Event that has been recorded once (its handle exists)
+        ex.event_after_build = event_after_build.cuda_event
     with torch.cuda.device(dev):
         B.check(B.lib().bhw_generate_device_ex(ctypes.byref(params), dev, _stream_ptr(torch, dev), int(n0), int(count),
                                                 ctypes.c_void_p(out.data_ptr()), ctypes.byref(ex)))

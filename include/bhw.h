@@ -79,8 +79,10 @@ typedef struct bhw_params {
 typedef struct bhw_exec {
     uint32_t struct_size;     /* sizeof(bhw_exec)                                          */
     uint32_t algo;            /* BHW_ALGO_*                                                */
-    void    *workspace;       /* device scratch (NULL: library-owned per-device scratch)   */
+    void    *workspace;       /* device scratch (NULL: library-owned scratch of this stream) */
     uint64_t workspace_bytes;
+    void    *event_after_build; /* optional hipEvent_t recorded on the stream between the table build and the
+                                   combine pass (per-kernel timing for profilers); NULL = none      */
 } bhw_exec;
 
 uint32_t    bhw_abi_version(void);

@@ -24,7 +24,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     assert ctypes.sizeof(B.BhwParams) == 4 * 10 + 4 * 7
-    assert ctypes.sizeof(B.BhwExec) == 24
+    assert ctypes.sizeof(B.BhwExec) == 32
 
 
 def test_strerror():
