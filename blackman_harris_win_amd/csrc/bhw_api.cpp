@@ -477,6 +477,35 @@ int bhw_sincos_to_host(const bhw_params *p, int device, uint64_t theta0, uint64_
     return rc;
 }
 
+// Development hooks (not part of the ABI in include/bhw.h): the two passes of the table strategy on their own,
+// for overlap experiments (tools/overlap_probe.py).
+int bhw_dbg_table_build(const bhw_params *p, int device, void *stream, void *ws)
+{
+    if (validate(p)) return BHW_ERR_BADARG;
+    BhwCordicCfg c;
+    resolve_cordic(p, c);
+    BhwWinCfg w;
+    resolve_window(p, w);
+    c.tab_split = bhwk_tile_applicable(c, w) ? 1u : 0u;
+    BhwLaunch l{device, stream};
+    return bhwk_table_build(l, c, (int32_t *)ws);
+}
+
+int bhw_dbg_table_combine(const bhw_params *p, int device, void *stream, const void *ws, int32_t *d_out)
+{
+    if (validate(p)) return BHW_ERR_BADARG;
+    BhwCordicCfg c;
+    resolve_cordic(p, c);
+    BhwWinCfg w;
+    resolve_window(p, w);
+    BhwLaunch l{device, stream};
+    if (bhwk_tile_applicable(c, w)) {
+        c.tab_split = 1u;
+        return bhwk_table_combine_tile(l, c, w, (const int32_t *)ws, d_out);
+    }
+    return bhwk_table_combine_fold(l, c, w, (const int32_t *)ws, d_out);
+}
+
 int bhw_release_device(int device)
 {
     std::lock_guard<std::mutex> lk(g_mu);
