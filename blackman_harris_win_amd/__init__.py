@@ -21,9 +21,9 @@ from .binding import (  # noqa: F401
     WIN_BH3, WIN_BH4, WIN_BH5, WIN_BH7, WIN_HAMMING, WIN_HANN,
     BhwError, BhwParams, coeffs_from_float, constant_tables, lib, lib_path, make_params,
 )
-from .selector import WinSelector, cordic, generate, generate_batched, shard_range, win_function  # noqa: F401
+from .selector import WinSelector, apply, cordic, generate, generate_batched, shard_range, win_function  # noqa: F401
 
 __all__ = [
-    "WinSelector", "win_function", "cordic", "generate", "generate_batched", "shard_range",
+    "WinSelector", "win_function", "cordic", "generate", "generate_batched", "apply", "shard_range",
     "make_params", "coeffs_from_float", "constant_tables", "BhwParams", "BhwError", "lib", "lib_path",
 ]

@@ -15,7 +15,7 @@ ABI_SYMBOLS = (
     "bhw_abi_version", "bhw_strerror", "bhw_last_error", "bhw_params_init", "bhw_params_validate",
     "bhw_coeffs_from_float", "bhw_constant_tables", "bhw_generate_device", "bhw_generate_device_ex",
     "bhw_workspace_bytes", "bhw_generate_batched_device", "bhw_sincos_device", "bhw_generate_to_host",
-    "bhw_sincos_to_host", "bhw_release_device",
+    "bhw_sincos_to_host", "bhw_release_device", "bhw_apply_device",
 )
 
 
@@ -86,6 +86,7 @@ def lib():
     L.bhw_generate_to_host.argtypes = [P, ci, u64, u64, i32p]
     L.bhw_sincos_to_host.argtypes = [P, ci, u64, u64, i32p, i32p]
     L.bhw_release_device.argtypes = [ci]
+    L.bhw_apply_device.argtypes = [P, ci, vp, u64, u64, i32p, i32p, u32]
     _lib = L
     return L
 

@@ -238,7 +238,7 @@ uint32_t pick_algo(const bhw_params *p, const BhwCordicCfg &c, uint64_t count, u
 }
 
 int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, uint64_t count, int32_t *d_out,
-                  const bhw_exec *ex)
+                  const bhw_exec *ex, const int32_t *apply_x = nullptr, uint32_t apply_shift = 0)
 {
     int rc = validate(p);
     if (rc) return rc;
@@ -249,6 +249,8 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
     BhwLaunch l{device, stream};
     BhwWinCfg w;
     resolve_window(p, w);
+    w.apply_x = apply_x;
+    w.apply_shift = apply_shift;
     if (p->sin_type == BHW_SIN_TAYLOR) {
         BhwTaylorCfg t;
         rc = resolve_taylor(p, device, stream, t);
@@ -285,11 +287,17 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
         if (he != hipSuccess) return fail_hip(he, "hipEventRecord(event_after_build)");
     }
     if (whole) {
-        // whole periods: quadrant-fold combine for the first, store-only replication for the rest
-        e = tiled ? bhwk_table_combine_tile(l, c, w, (const int32_t *)ws, d_out)
-                  : bhwk_table_combine_fold(l, c, w, (const int32_t *)ws, d_out);
-        if (e) return fail_hip(e, "table combine (fold) launch");
-        if (count > N) {
+        // whole periods: quadrant-fold combine for the first, store-only replication for the rest; with the fused
+        // apply every period has its own x, so the combine pass runs once per period on the one table
+        const uint64_t periods = apply_x ? count / N : 1;
+        for (uint64_t f = 0; f < periods; ++f) {
+            if (apply_x) w.apply_x = apply_x + f * N;
+            int32_t *o = d_out + f * N;
+            e = tiled ? bhwk_table_combine_tile(l, c, w, (const int32_t *)ws, o)
+                      : bhwk_table_combine_fold(l, c, w, (const int32_t *)ws, o);
+            if (e) return fail_hip(e, "table combine (fold) launch");
+        }
+        if (!apply_x && count > N) {
             e = bhwk_replicate(l, d_out, N, (uint32_t)(count / N - 1), d_out + N);
             if (e) return fail_hip(e, "replicate launch");
         }
@@ -382,6 +390,17 @@ int bhw_generate_device_ex(const bhw_params *p, int device, void *hip_stream, ui
                            int32_t *d_out, const bhw_exec *ex)
 {
     return generate_impl(p, device, hip_stream, n0, count, d_out, ex);
+}
+
+int bhw_apply_device(const bhw_params *p, int device, void *hip_stream, uint64_t n0, uint64_t count,
+                     const int32_t *d_x, int32_t *d_y, uint32_t shift)
+{
+    if (count && (!d_x || !d_y)) return fail(BHW_ERR_BADARG, "d_x / d_y is NULL");
+    if (shift > 62) return fail(BHW_ERR_BADARG, "shift %u > 62", shift);
+    const uintptr_t xa = (uintptr_t)d_x, ya = (uintptr_t)d_y, bytes = (uintptr_t)count * 4u;
+    if (count && xa < ya + bytes && ya < xa + bytes)
+        return fail(BHW_ERR_BADARG, "d_y must not overlap d_x (tile seams recompute a few samples)");
+    return generate_impl(p, device, hip_stream, n0, count, d_y, nullptr, d_x, shift);
 }
 
 uint64_t bhw_workspace_bytes(const bhw_params *p, uint64_t n0, uint64_t count, uint32_t algo)

@@ -29,7 +29,10 @@ struct BhwWinCfg {
     int32_t  aa[8];
     uint32_t n_terms;
     uint32_t combine;     // BHW_COMBINE_*
-    uint32_t pad[2];
+    // fused apply: when apply_x != NULL the kernels store (x[i] * w[i]) >> apply_shift instead of w[i]
+    uint32_t apply_shift;
+    uint32_t pad;
+    const int32_t *apply_x;
 };
 
 // Taylor feeder (src/taylor_sincos.vhd + src/tay1_order.vhd).

@@ -105,6 +105,15 @@ __device__ __forceinline__ int32_t combine_final(int64_t acc, uint32_t W, uint32
     return (int32_t)wrap_bits(acc, W);
 }
 
+// Output stage.  Plain generation stores the coefficient; the fused apply (the window feeds a
+// multiplier in front of an FFT) stores (x[i] * w[i]) >> shift -- exact 64-bit product like int_multNxN_dsp48.vhd:102,
+// floor shift, low 32 bits -- so the coefficient vector never round-trips through HBM.
+__device__ __forceinline__ void emit(const BhwWinCfg &win, int32_t *__restrict__ out, uint64_t idx, int32_t w)
+{
+    if (win.apply_x) w = (int32_t)(((int64_t)win.apply_x[idx] * (int64_t)w) >> win.apply_shift);
+    out[idx] = w;
+}
+
 template <typename T>
 __device__ __forceinline__ void stage_lut(const BhwCordicCfg &cfg, T *lut_s)
 {
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(BhwCordicCfg cfg, BhwWinCfg w
         cordic_full<T>(cfg, lut_s, theta, c, s);
         combine_term(acc, win.aa[k], c, k, cfg.dat_width, win.combine);
     }
-    out[i] = combine_final(acc, cfg.dat_width, win.combine, win.n_terms);
+    emit(win, out, i, combine_final(acc, cfg.dat_width, win.combine, win.n_terms));
 }
 
 // sin/cos sweep: cordic() alone.
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(kBlock) void k_direct_fast(BhwCordicCfg cfg, BhwWin
         quadrant_map(theta >> (pw - 2), (int32_t)(x >> cfg.out_shr), (int32_t)(y >> cfg.out_shr), cfg.ones_neg, c, s);
         combine_term(acc, win.aa[k], c, k, cfg.dat_width, win.combine);
     }
-    out[i] = combine_final(acc, cfg.dat_width, win.combine, win.n_terms);
+    emit(win, out, i, combine_final(acc, cfg.dat_width, win.combine, win.n_terms));
 }
 
 // sin/cos sweep, fast form (cordic() alone in the mad-form rotation).
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(kBlock) void k_table_combine(BhwCordicCfg cfg, BhwW
         quadrant_map(theta >> (pw - 2), cs.x, cs.y, cfg.ones_neg, c, s);
         combine_term(acc, win.aa[k], c, k, cfg.dat_width, win.combine);
     }
-    out[i] = combine_final(acc, cfg.dat_width, win.combine, win.n_terms);
+    emit(win, out, i, combine_final(acc, cfg.dat_width, win.combine, win.n_terms));
 }
 
 // Table strategy, pass 2, whole-period form ("quadrant fold").  Lane r in [0, N/4) owns the four
@@ -393,10 +402,10 @@ __global__ __launch_bounds__(kBlock) void k_table_combine_fold(BhwCordicCfg cfg,
         acc2 += q2 == 0 ? p0 : q2 == 1 ? p1 : q2 == 2 ? p2 : p3;
         acc3 += q3 == 0 ? p0 : q3 == 1 ? p1 : q3 == 2 ? p2 : p3;
     }
-    out[r] = combine_final(acc0, W, win.combine, win.n_terms);
-    out[r + quarter] = combine_final(acc1, W, win.combine, win.n_terms);
-    out[r + 2u * quarter] = combine_final(acc2, W, win.combine, win.n_terms);
-    out[r + 3u * quarter] = combine_final(acc3, W, win.combine, win.n_terms);
+    emit(win, out, r, combine_final(acc0, W, win.combine, win.n_terms));
+    emit(win, out, r + quarter, combine_final(acc1, W, win.combine, win.n_terms));
+    emit(win, out, r + 2u * quarter, combine_final(acc2, W, win.combine, win.n_terms));
+    emit(win, out, r + 3u * quarter, combine_final(acc3, W, win.combine, win.n_terms));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -546,11 +555,7 @@ __global__ __launch_bounds__(kTileThreads) void k_table_combine_tile(BhwCordicCf
                 int32_t v;
                 if constexpr (MODE == 2) v = combine_final((int64_t)acc[b][h][j], W, win.combine, win.n_terms);
                 else v = (int32_t)((uint32_t)acc[b][h][j] << (32u - W)) >> (32u - W);   // (win_t)(...) wrap to W bits
-#ifdef BHW_NT_STORE
-                __builtin_nontemporal_store(v, &out[r + (uint32_t)h * H + (uint32_t)j * E]);
-#else
-                out[r + (uint32_t)h * H + (uint32_t)j * E] = v;
-#endif
+                emit(win, out, r + (uint32_t)h * H + (uint32_t)j * E, v);
             }
     }
 }
@@ -639,7 +644,7 @@ __global__ __launch_bounds__(kBlock) void k_taylor_window(BhwTaylorCfg t, BhwWin
         }
         combine_term(acc, win.aa[k], c, k, t.dat_width, win.combine);
     }
-    out[i] = combine_final(acc, t.dat_width, win.combine, win.n_terms);
+    emit(win, out, i, combine_final(acc, t.dat_width, win.combine, win.n_terms));
 }
 
 __global__ __launch_bounds__(kBlock) void k_taylor_sincos(BhwTaylorCfg t, uint64_t theta0, uint64_t count,

@@ -64,6 +64,23 @@ def generate(params, n0, count, *, device=None, out=None, algo=B.ALGO_AUTO, work
     return out
 
 
+def apply(params, x, *, n0=0, shift=None, out=None):
+    """Fused apply: y[i] = (x[i] * w[n0+i]) >> shift without materialising w (bhw_apply_device).
+    `shift` defaults to dat_width - 1 (unit gain for a full-scale window)."""
+    torch = _torch()
+    if x.dtype != torch.int32 or not x.is_cuda or not x.is_contiguous():
+        raise ValueError("x must be a contiguous int32 CUDA tensor")
+    dev = x.device.index
+    if out is None:
+        out = torch.empty_like(x)
+    if shift is None:
+        shift = params.dat_width - 1
+    with torch.cuda.device(dev):
+        B.check(B.lib().bhw_apply_device(ctypes.byref(params), dev, _stream_ptr(torch, dev), int(n0), x.numel(),
+                                          ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()), int(shift)))
+    return out
+
+
 def generate_batched(params, frames, *, device=None, out=None):
     """frames x 2^phi_width coefficients: one period computed, then replicated (bhw_generate_batched_device)."""
     torch = _torch()

@@ -115,6 +115,13 @@ int bhw_generate_device_ex(const bhw_params *p, int device, void *hip_stream,
 /* Device scratch the given call would need with `algo` (0 for the direct strategy). */
 uint64_t bhw_workspace_bytes(const bhw_params *p, uint64_t n0, uint64_t count, uint32_t algo);
 
+/* Fused apply (the step after the path in every consumer -- the window multiplies the samples in
+ * front of an FFT).  d_y[i] = (d_x[i] * w[n0+i]) >> shift with the exact 64-bit product (as int_multNxN_dsp48,
+ * src/int_multNxN_dsp48.vhd:102), floor shift (0..62) and the low 32 bits stored; the coefficients are generated
+ * on the fly and never written to HBM.  d_y must not overlap d_x. */
+int bhw_apply_device(const bhw_params *p, int device, void *hip_stream, uint64_t n0, uint64_t count,
+                     const int32_t *d_x, int32_t *d_y, uint32_t shift);
+
 /* `frames` back-to-back periods of the coefficient stream (the streaming-frame workload:
  * ENABLE held for frames * 2^phi_width clocks).  One period is computed, then replicated by a
  * store-only kernel: d_out holds frames * 2^phi_width int32. */

@@ -231,6 +231,35 @@ def test_concurrent_streams_use_separate_library_scratch(torch):
     assert B.lib().bhw_release_device(0) == 0
 
 
+# ---- fused apply y = (x * w) >> shift ------------------------------------------------
+@pytest.mark.parametrize("win,pw,w,model,combine,n0,count,shift", [
+    (7, 16, 32, B.MODEL_HLS, B.COMBINE_HLS, 0, 1 << 16, 31),        # whole period, tile path
+    (7, 16, 32, B.MODEL_HLS, B.COMBINE_HLS, 0, 3 << 16, 30),        # three periods of samples, one table
+    (4, 17, 24, B.MODEL_CPP, B.COMBINE_HLS, 12345, 50000, 23),      # unaligned range, general table path
+    (5, 12, 16, B.MODEL_VHDL, B.COMBINE_VHDL, 0, 4096, 15),         # whole period, plain fold path
+    (3, 10, 24, B.MODEL_HLS, B.COMBINE_HLS, 7, 700, 0),             # short: direct path, shift 0
+    (1, 12, 16, B.MODEL_HLS, B.COMBINE_VHDL, 0, 4096, 62),          # extreme shift
+])
+def test_fused_apply_matches_oracle(torch, win, pw, w, model, combine, n0, count, shift):
+    import blackman_harris_win_amd as bhw
+    p = B.make_params(win, pw, w, model=model, combine=combine)
+    rng = np.random.default_rng(count + shift)
+    x = rng.integers(-(1 << 31), 1 << 31, count, dtype=np.int64).astype(np.int32)
+    wv = O.generate(O.from_bhw(p), n0, count).astype(np.int64)
+    want = ((x.astype(np.int64) * wv) >> shift).astype(np.int32)            # exact product, floor shift, low 32 bits
+    got = bhw.apply(p, torch.from_numpy(x).cuda(), n0=n0, shift=shift).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_fused_apply_rejects_aliasing(torch):
+    p = B.make_params(4, 12, 24)
+    x = torch.zeros(4096, dtype=torch.int32, device="cuda")
+    L = B.lib()
+    rc = L.bhw_apply_device(ctypes.byref(p), 0, None, 0, 4096, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(x.data_ptr()), 23)
+    assert rc == -1 and b"overlap" in L.bhw_last_error()
+    assert L.bhw_apply_device(ctypes.byref(p), 0, None, 0, 4096, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(x.data_ptr() + 4 * 4096), 63) == -1
+
+
 # ---- the selector / HLS-top mirrors -------------------------------------------------------------------
 def test_win_selector_streaming_counter(torch):
     from blackman_harris_win_amd import WinSelector

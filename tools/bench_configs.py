@@ -47,6 +47,10 @@ def main():
     res["C4_1024x_bh4_2^16_replicate"] = {"ms": ms, "Gsamples/s": (1 << 26) / ms / 1e6, "GB/s": 4 * (1 << 26) / ms / 1e6}
     ms = timeit(lambda: bhw.generate(p4, 0, 1 << 26, out=o4.view(-1), algo=B.ALGO_DIRECT), iters=3, warm=1)
     res["C4_1024x_bh4_2^16_recompute_direct"] = {"ms": ms, "Gsamples/s": (1 << 26) / ms / 1e6}
+    x = torch.randint(-(1 << 31), (1 << 31) - 1, (1 << 26,), dtype=torch.int32, device="cuda")
+    ms = timeit(lambda: bhw.apply(p3, x, out=o3, shift=31), iters=10, warm=2)
+    res["fused_apply_bh7_2^26_32bit"] = {"ms": ms, "Gsamples/s": (1 << 26) / ms / 1e6,
+                                         "note": "y = (x*w) >> 31, reads x, writes y, no coefficient vector in HBM"}
     pc = bhw.make_params(1, 26, 32, model=B.MODEL_CPP)
     ms = timeit(lambda: bhw.cordic(pc, 0, 1 << 26), iters=5, warm=1)
     res["sincos_cpp_2^26_32bit"] = {"ms": ms, "Gphases/s": (1 << 26) / ms / 1e6}
