@@ -46,16 +46,20 @@ def pdict(p):
     return d
 
 
-def c3_shard(g):
-    cache = f"/tmp/c3_shard{g}.npy"
+def c3_shard(g, model=O.MODEL_HLS):
+    cache = f"/tmp/c3_shard{g}.npy" if model == O.MODEL_HLS else f"/tmp/c3_m{model}_shard{g}.npy"
     if os.path.exists(cache):
         a = np.load(cache)
     else:
-        a = O.generate(O.oparams(7, 26, 32), g << 23, 1 << 23)
+        a = O.generate(O.oparams(7, 26, 32, model=model), g << 23, 1 << 23)
         np.save(cache, a)
     st = stats(a)
     st["strided_1024"] = [int(v) for v in a[:: (1 << 23) // 1024][:1024]]
     return g, st
+
+
+def c3_shard_cpp(g):
+    return c3_shard(g, O.MODEL_CPP)
 
 
 def main():
@@ -157,6 +161,14 @@ def main():
     E["C3_bh7_26_32"] = {"source": "survey", "what": "shard g = [g*2^23, (g+1)*2^23); sums/min/max/sparse from SURVEY App. B, "
                          "md5/fnv/strided samples from the oracle that reproduces them", "params": pdict(p),
                          "shards": [shards[g] for g in range(8)], "sparse": {str(k): v for k, v in sparse.items()}}
+
+    # the same headline window with the cpp model's cosines (model A is the one pinned by oracle/_ref)
+    with Pool(8) as pool:
+        shards_cpp = dict(pool.map(c3_shard_cpp, range(8)))
+    pc = O.oparams(7, 26, 32, model=O.MODEL_CPP)
+    E["C3cpp_bh7_26_32"] = {"source": "oracle", "note": "BH-7 2^26/32-bit with model CPP cosines (oracle pinned bit-for-bit to the "
+                            "reference's cordic() via oracle/_ref) in the HLS cosine-sum rule; per-shard checksums",
+                            "params": pdict(pc), "shards": [shards_cpp[g] for g in range(8)]}
 
     # ---- oracle-only vectors: no runnable reference (parity unpinned) or derived configurations --------
     def oracle_only(name, p, n0, count, keep=True, note="parity unpinned: restated from the VHDL, no simulator here"):

@@ -338,6 +338,19 @@ def test_c3_full_64m(torch, golden):
     del full
 
 
+def test_c3_full_64m_model_cpp(torch, golden):
+    """The headline window with the cpp model's cosines (the model pinned by the reference's own cordic() build)."""
+    import blackman_harris_win_amd as bhw
+    e = golden["C3cpp_bh7_26_32"]
+    p = B.make_params(7, 26, 32, model=B.MODEL_CPP)
+    full = bhw.generate(p, 0, 1 << 26, algo=B.ALGO_TABLE)
+    for g in range(8):
+        sh = full[g << 23:(g + 1) << 23]
+        assert int(sh.sum(dtype=torch.int64)) == e["shards"][g]["sum"]
+        assert _md5(sh.cpu().numpy()) == e["shards"][g]["md5"]
+    del full
+
+
 def test_c3_model_cpp_full_sincos_quadrant_property(torch):
     """2^26 phases at 32 bits, model CPP: the three upper quadrants are the quadrant-mapped first one."""
     import blackman_harris_win_amd as bhw
