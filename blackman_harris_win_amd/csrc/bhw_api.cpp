@@ -279,7 +279,7 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
     const uint64_t N = 1ull << p->phi_width;
     const bool whole = (n0 % N == 0 && count % N == 0);
     const bool tiled = whole && bhwk_tile_applicable(c, w);
-    c.tab_split = tiled ? 1u : 0u;
+    c.tab_split = (tiled && c.z_shr == 0) ? 1u : 0u;
     int e = bhwk_table_build(l, c, (int32_t *)ws);
     if (e) return fail_hip(e, "table build launch");
     if (ex && ex->event_after_build) {
@@ -505,7 +505,7 @@ int bhw_dbg_table_build(const bhw_params *p, int device, void *stream, void *ws)
     resolve_cordic(p, c);
     BhwWinCfg w;
     resolve_window(p, w);
-    c.tab_split = bhwk_tile_applicable(c, w) ? 1u : 0u;
+    c.tab_split = (bhwk_tile_applicable(c, w) && c.z_shr == 0) ? 1u : 0u;
     BhwLaunch l{device, stream};
     return bhwk_table_build(l, c, (int32_t *)ws);
 }
@@ -519,7 +519,7 @@ int bhw_dbg_table_combine(const bhw_params *p, int device, void *stream, const v
     resolve_window(p, w);
     BhwLaunch l{device, stream};
     if (bhwk_tile_applicable(c, w)) {
-        c.tab_split = 1u;
+        c.tab_split = c.z_shr == 0 ? 1u : 0u;
         return bhwk_table_combine_tile(l, c, w, (const int32_t *)ws, d_out);
     }
     return bhwk_table_combine_fold(l, c, w, (const int32_t *)ws, d_out);

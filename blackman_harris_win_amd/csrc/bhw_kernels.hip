@@ -195,7 +195,7 @@ __global__ __launch_bounds__(kBlock) void k_table_build(BhwCordicCfg cfg, uint32
 // rotation 0 always adds (z0 >= 0), giving x1 = y1 = x0 and z1 = z0 - lut[0], which fits int32.
 // ---------------------------------------------------------------------------------------
 constexpr int kPrefixMax = 20;      // deepest rotation a 64-leaf group is followed to in phase 1
-constexpr int kGroupsPerWg = 64;    // phase 1: one group per lane of the first wave
+constexpr int kGroupsPerWg = 64;    // phase 1: at most one group per lane of the first wave (plan.groups_per_wg <= 64)
 constexpr int kBuildThreads = 256;  // phase 2: four waves, 16 groups each
 
 struct BhwBuildPlan {
@@ -206,6 +206,8 @@ struct BhwBuildPlan {
     uint32_t out_shr;
     uint32_t log2_entries;
     uint32_t tab_split;
+    uint32_t groups_per_wg;   // 4, 16 or 64: small tables use small workgroups so the grid still fills the chip
+    uint32_t pad;
     int64_t  x0;
 };
 
@@ -240,11 +242,12 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
 
     constexpr int n_iter = NITER;
     const uint32_t s = plan.z_shl;
-    const uint32_t group0 = blockIdx.x * kGroupsPerWg;
+    const uint32_t gpw = plan.groups_per_wg;
+    const uint32_t group0 = blockIdx.x * gpw;
     const uint32_t n_groups = plan.entries >> 6;
 
     // ---- phase 1: shared prefix of each 64-leaf group ----
-    if (threadIdx.x < kGroupsPerWg) {
+    if (threadIdx.x < gpw) {
         const uint32_t g = group0 + threadIdx.x;
         const uint32_t u_first = g << 6;
         int64_t x = plan.x0, y = plan.x0;                                        // after rotation 0
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
 
     // ---- phase 2: one wave per group, one lane per leaf, remaining rotations only ----
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    for (uint32_t gi = wave; gi < (uint32_t)kGroupsPerWg; gi += kBuildThreads / 64) {
+    for (uint32_t gi = wave; gi < gpw; gi += kBuildThreads / 64) {
         const uint32_t g = group0 + gi;
         if (g >= n_groups) break;
         int64_t x = gx[gi], y = gy[gi];
@@ -420,17 +423,6 @@ __global__ __launch_bounds__(kBlock) void k_table_combine_fold(BhwCordicCfg cfg,
 // The 15 run offsets are ~E/15 apart, so tiles m = 0..n_tiles-1 cover the ring once; the few entries
 // covered twice at the seams are recomputed with identical results (idempotent stores).
 // ---------------------------------------------------------------------------------------
-#ifdef BHW_NT_LOAD
-__device__ __forceinline__ int2 bhw_nt_load(const int2 *p)
-{
-    typedef int v2i __attribute__((ext_vector_type(2)));
-    const v2i v = __builtin_nontemporal_load(reinterpret_cast<const v2i *>(p));
-    return make_int2(v.x, v.y);
-}
-#define BHW_TABLE_LOAD(p) bhw_nt_load(p)
-#else
-#define BHW_TABLE_LOAD(p) (*(p))
-#endif
 #ifndef BHW_TILE_THREADS
 #define BHW_TILE_THREADS 768
 #endif
@@ -512,21 +504,15 @@ __global__ __launch_bounds__(kTileThreads) void k_table_combine_tile(BhwCordicCf
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[b][h][j] = (acc_t)win.aa[0];
 
-#ifdef BHW_TILE_SYNC
-#define BHW_TILE_ALIGN() if (kParts > 1) __syncthreads()
-#else
-#define BHW_TILE_ALIGN()
-#endif
 #define BHW_TILE_HARMONIC(K)                                                                             \
     if (win.n_terms > K) {                                                                               \
         constexpr int NG = (K & 1) ? 2 : 1;                                                              \
-        BHW_TILE_ALIGN();   /* keep the thread groups in step so sibling runs hit the same lines together */ \
         int2 cs[NR][NG];                                                                                 \
         _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
             const uint32_t r = (rbase + offs[b]) & hmask;                                             \
             _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                             \
                 const uint32_t theta = ((uint32_t)K * (r + (uint32_t)g * H)) & mask;                     \
-                cs[b][g] = BHW_TABLE_LOAD(&table[tab_index(theta & emask, lq, 1u)]);                     \
+                cs[b][g] = table[tab_index((theta & emask) >> cfg.z_shr, lq - cfg.z_shr, cfg.tab_split)]; \
             }                                                                                            \
         }                                                                                                \
         _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
@@ -728,8 +714,12 @@ int bhwk_replicate(const BhwLaunch &l, const int32_t *d_frame, uint64_t frame_le
     const bool vec = (frame_len % 4 == 0) && (((uintptr_t)d_frame | (uintptr_t)d_out) % 16 == 0);
     const uint64_t items = vec ? frame_len / 4 : frame_len;
     const unsigned gx = grid_for(items);
-    // enough workgroups to fill 256 CUs several times over, without one block per (chunk, frame)
-    unsigned gy = (unsigned)((4096 + gx - 1) / gx);
+    // the fill rate on MI355X peaks with >= 64K workgroups in flight (profiles/r01_ubench_gfx950.txt: 5.8 TB/s at 2K
+    // blocks, 6.95 TB/s at 64K), so spread the frames over grid.y until there are about that many
+#ifndef BHW_REPL_BLOCKS
+#define BHW_REPL_BLOCKS 65536
+#endif
+    unsigned gy = (unsigned)((BHW_REPL_BLOCKS + gx - 1) / gx);
     if (gy > frames) gy = frames;
     if (gy < 1) gy = 1;
     if (gy > 65535) gy = 65535;
@@ -756,7 +746,9 @@ int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table
         plan.tab_split = c.tab_split;
         plan.x0 = c.x0;
         const unsigned groups = entries >> 6;
-        const dim3 grid((groups + kGroupsPerWg - 1) / kGroupsPerWg), block(kBuildThreads);
+        plan.groups_per_wg = groups >= 64u * 1024u ? 64u : groups >= 16u * 1024u ? 16u : 4u;
+        plan.pad = 0;
+        const dim3 grid((groups + plan.groups_per_wg - 1) / plan.groups_per_wg), block(kBuildThreads);
         switch (c.n_iter) {
 #define BHW_CASE(N) case N: hipLaunchKernelGGL(k_table_build_shared<N>, grid, block, 0, st, plan, (int2 *)d_table); break;
             BHW_CASE(7) BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14)
@@ -803,8 +795,10 @@ static uint32_t inv_mod_pow2(uint32_t a, uint32_t log2m)
 bool bhwk_tile_applicable(const BhwCordicCfg &c, const BhwWinCfg &w)
 {
     // the 15-run tile with 64-bit sums (VHDL rule at 6+ harmonics) does not fit the register file: plain fold instead
-    if (w.combine != BHW_COMBINE_HLS && w.n_terms > 5) return false;
-    return c.z_shr == 0 && c.phi_width >= 16 && c.phi_width <= 30;
+    // With dropped phase bits (z_shr > 0) consecutive lanes share table entries, so the gathers are dense on their
+    // own: such tables take the one-run form of the kernel over the natural layout.
+    if (c.z_shr == 0 && w.combine != BHW_COMBINE_HLS && w.n_terms > 5) return false;
+    return c.phi_width >= 16 && c.phi_width <= 30;
 }
 
 int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out)
@@ -813,18 +807,14 @@ int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const Bhw
     hipStream_t st = (hipStream_t)l.stream;
     const uint32_t lq = c.phi_width - 2, E = 1u << (lq - 1);   // the lane ring is [0, N/8): each lane owns r and r + N/8
     const uint32_t inv3 = inv_mod_pow2(3, lq - 1), inv5 = inv_mod_pow2(5, lq - 1);
-    const int nb3 = w.n_terms > 3 ? 3 : 1, nb5 = w.n_terms > 5 ? 5 : 1;
+    const int nb3 = (c.z_shr == 0 && w.n_terms > 3) ? 3 : 1, nb5 = (c.z_shr == 0 && w.n_terms > 5) ? 5 : 1;
     const int nb = nb3 * nb5;
     BhwTilePlan tp;
     uint32_t sorted[15];
     for (int i5 = 0; i5 < nb5; ++i5)
         for (int i3 = 0; i3 < nb3; ++i3) {
             const uint32_t o = (uint32_t)(((uint64_t)i3 * inv3 + (uint64_t)i5 * inv5) & (E - 1u));
-#ifdef BHW_RUNS_BY_I5
-            tp.offs[i3 + nb3 * i5] = o;      // thread group = consecutive (i3, i5) pairs
-#else
             tp.offs[i5 + nb5 * i3] = o;      // thread group p holds the five inv5-siblings of i3 = p: k = 5 is dense per thread
-#endif
             sorted[i3 + nb3 * i5] = o;
         }
     for (int i = nb; i < 16; ++i) tp.offs[i] = tp.offs[nb - 1];

@@ -135,7 +135,10 @@ TILE_CASES = [(1, 16, 16, B.MODEL_HLS, B.COMBINE_HLS), (3, 16, 24, B.MODEL_HLS, 
               (4, 17, 24, B.MODEL_CPP, B.COMBINE_HLS), (5, 16, 32, B.MODEL_HLS, B.COMBINE_HLS),
               (7, 16, 32, B.MODEL_VHDL, B.COMBINE_VHDL), (7, 17, 30, B.MODEL_CPP, B.COMBINE_VHDL),
               (7, 16, 31, B.MODEL_HLS, B.COMBINE_VHDL), (4, 18, 16, B.MODEL_HLS, B.COMBINE_HLS),
-              (7, 18, 20, B.MODEL_VHDL, B.COMBINE_HLS), (2, 16, 24, B.MODEL_HLS, B.COMBINE_HLS)]
+              (7, 18, 20, B.MODEL_VHDL, B.COMBINE_HLS), (2, 16, 24, B.MODEL_HLS, B.COMBINE_HLS),
+              # phase bits dropped (PW >= W): small shared table, one-run form of the tile kernel
+              (7, 20, 12, B.MODEL_CPP, B.COMBINE_HLS), (7, 18, 16, B.MODEL_VHDL, B.COMBINE_VHDL),
+              (5, 19, 14, B.MODEL_CPP, B.COMBINE_VHDL), (4, 18, 16, B.MODEL_HLS, B.COMBINE_HLS)]
 
 
 @pytest.mark.parametrize("win,pw,w,model,combine", TILE_CASES)

@@ -51,6 +51,11 @@ def main():
     ms = timeit(lambda: bhw.apply(p3, x, out=o3, shift=31), iters=10, warm=2)
     res["fused_apply_bh7_2^26_32bit"] = {"ms": ms, "Gsamples/s": (1 << 26) / ms / 1e6,
                                          "note": "y = (x*w) >> 31, reads x, writes y, no coefficient vector in HBM"}
+    for name, w, model in (("cpp_16bit", 16, B.MODEL_CPP), ("vhdl_16bit", 16, B.MODEL_VHDL), ("cpp_24bit", 24, B.MODEL_CPP)):
+        pn = bhw.make_params(7, 26, w, model=model)
+        ms = timeit(lambda: bhw.generate(pn, 0, 1 << 26, out=o3, algo=B.ALGO_TABLE), iters=10, warm=2)
+        res[f"narrow_bh7_2^26_{name}_table"] = {"ms": ms, "Gsamples/s": (1 << 26) / ms / 1e6, "GB/s": 4 * (1 << 26) / ms / 1e6,
+                                               "table_entries": 1 << (w - 2)}
     pc = bhw.make_params(1, 26, 32, model=B.MODEL_CPP)
     ms = timeit(lambda: bhw.cordic(pc, 0, 1 << 26), iters=5, warm=1)
     res["sincos_cpp_2^26_32bit"] = {"ms": ms, "Gphases/s": (1 << 26) / ms / 1e6}
