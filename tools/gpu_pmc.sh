@@ -29,7 +29,7 @@ for k,v in agg.items():
 # on the table-build kernel, which writes exactly 8 B x entries).
 step=0.0
 for k,v in summary.items():
-    if "rocclr" in k: continue
+    if "bhw" not in k.lower() and "k_table" not in k and "k_direct" not in k: continue   # only this library's kernels
     f=2*1024*v.get("FETCH_SIZE",{}).get("mean",0.0); w=1024*v.get("WRITE_SIZE",{}).get("mean",0.0)
     v["hbm_bytes_per_launch"]={"read":f,"write":w,"total":f+w}
     step+=f+w
