@@ -798,7 +798,11 @@ bool bhwk_tile_applicable(const BhwCordicCfg &c, const BhwWinCfg &w)
     // With dropped phase bits (z_shr > 0) consecutive lanes share table entries, so the gathers are dense on their
     // own: such tables take the one-run form of the kernel over the natural layout.
     if (c.z_shr == 0 && w.combine != BHW_COMBINE_HLS && w.n_terms > 5) return false;
-    return c.phi_width >= 16 && c.phi_width <= 30;
+    // below 2^20 coefficients a tile grid leaves most CUs idle; the one-lane-per-four fold kernel has 8-24x more workgroups
+#ifndef BHW_TILE_MIN_PW
+#define BHW_TILE_MIN_PW 20
+#endif
+    return c.phi_width >= BHW_TILE_MIN_PW && c.phi_width <= 30;
 }
 
 int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out)

@@ -130,7 +130,7 @@ def test_custom_weights_and_wrapping_sum(torch):
         assert np.array_equal(gpu_generate(p, 0, 1024, algo), O.generate(O.from_bhw(p), 0, 1024))
 
 
-# ---- whole-period calls at PW >= 16 take the super-tile combine (1-, 3- and 15-run tiles; 32/64-bit sums) ----
+# ---- whole-period calls: fold kernel below 2^20 coefficients, gather tiles (1-, 3-, 15-run; 32/64-bit sums) from 2^20 ----
 TILE_CASES = [(1, 16, 16, B.MODEL_HLS, B.COMBINE_HLS), (3, 16, 24, B.MODEL_HLS, B.COMBINE_VHDL),
               (4, 17, 24, B.MODEL_CPP, B.COMBINE_HLS), (5, 16, 32, B.MODEL_HLS, B.COMBINE_HLS),
               (7, 16, 32, B.MODEL_VHDL, B.COMBINE_VHDL), (7, 17, 30, B.MODEL_CPP, B.COMBINE_VHDL),
@@ -138,7 +138,10 @@ TILE_CASES = [(1, 16, 16, B.MODEL_HLS, B.COMBINE_HLS), (3, 16, 24, B.MODEL_HLS, 
               (7, 18, 20, B.MODEL_VHDL, B.COMBINE_HLS), (2, 16, 24, B.MODEL_HLS, B.COMBINE_HLS),
               # phase bits dropped (PW >= W): small shared table, one-run form of the tile kernel
               (7, 20, 12, B.MODEL_CPP, B.COMBINE_HLS), (7, 18, 16, B.MODEL_VHDL, B.COMBINE_VHDL),
-              (5, 19, 14, B.MODEL_CPP, B.COMBINE_VHDL), (4, 18, 16, B.MODEL_HLS, B.COMBINE_HLS)]
+              (5, 19, 14, B.MODEL_CPP, B.COMBINE_VHDL), (4, 18, 16, B.MODEL_HLS, B.COMBINE_HLS),
+              # N >= 2^20: tile kernel proper (1-, 3-run tiles, 64-bit sums, dropped phase bits)
+              (1, 20, 16, B.MODEL_CPP, B.COMBINE_HLS), (3, 20, 24, B.MODEL_HLS, B.COMBINE_VHDL),
+              (5, 20, 30, B.MODEL_VHDL, B.COMBINE_VHDL), (7, 21, 12, B.MODEL_CPP, B.COMBINE_VHDL)]
 
 
 @pytest.mark.parametrize("win,pw,w,model,combine", TILE_CASES)
