@@ -255,6 +255,21 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
         BhwTaylorCfg t;
         rc = resolve_taylor(p, device, stream, t);
         if (rc) return rc;
+        const uint64_t NT = 1ull << p->phi_width;
+        if (p->phi_width >= 5 && n0 % NT == 0 && count % NT == 0) {
+            // whole periods: quadrant-fold kernel per period (fused apply) or once + store-only replication
+            const uint64_t periods = apply_x ? count / NT : 1;
+            for (uint64_t f = 0; f < periods; ++f) {
+                if (apply_x) w.apply_x = apply_x + f * NT;
+                int e = bhwk_taylor_window_fold(l, t, w, d_out + f * NT);
+                if (e) return fail_hip(e, "taylor window (fold) launch");
+            }
+            if (!apply_x && count > NT) {
+                int e = bhwk_replicate(l, d_out, NT, (uint32_t)(count / NT - 1), d_out + NT);
+                if (e) return fail_hip(e, "replicate launch");
+            }
+            return BHW_OK;
+        }
         int e = bhwk_taylor_window(l, t, w, n0, count, d_out);
         return e ? fail_hip(e, "taylor window launch") : BHW_OK;
     }

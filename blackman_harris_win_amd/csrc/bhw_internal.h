@@ -66,5 +66,7 @@ int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const Bhw
 bool bhwk_tile_applicable(const BhwCordicCfg &c, const BhwWinCfg &w);
 int bhwk_taylor_window(const BhwLaunch &l, const BhwTaylorCfg &t, const BhwWinCfg &w,
                        uint64_t n0, uint64_t count, int32_t *d_out);
+// one whole period [0, 2^PW) with the quadrant fold (PW >= 5)
+int bhwk_taylor_window_fold(const BhwLaunch &l, const BhwTaylorCfg &t, const BhwWinCfg &w, int32_t *d_out);
 int bhwk_taylor_sincos(const BhwLaunch &l, const BhwTaylorCfg &t, uint64_t theta0, uint64_t count,
                        int32_t *d_sin, int32_t *d_cos);

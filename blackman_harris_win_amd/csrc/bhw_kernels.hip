@@ -572,10 +572,10 @@ __global__ __launch_bounds__(kBlock) void k_replicate4(const int32_t *__restrict
 // Taylor feeder: quarter-wave ROM + 1st-order correction (src/taylor_sincos.vhd:141-253,
 // src/tay1_order.vhd:112-146,501-502,585-616).
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void taylor_full(const BhwTaylorCfg &t, uint32_t cnt, int32_t &oc, int32_t &os)
+// first-quadrant part: (sin', cos') of the ROM entry + 1st-order correction for the phase bits below the quadrant field
+__device__ __forceinline__ void taylor_q1(const BhwTaylorCfg &t, const int2 *rom, uint32_t cnt, int64_t &s, int64_t &c)
 {
     const uint32_t pw = t.phi_width, W = t.dat_width, L = t.lut_size;
-    const uint32_t q = cnt >> (pw - 2);
     uint32_t addr, f = 0;
     if (t.mode == 0)      addr = (cnt & ((1u << (pw - 2)) - 1u)) << (L - pw + 2);     // taylor_sincos.vhd:157-161
     else if (t.mode == 1) addr = cnt & ((1u << L) - 1u);                             // :164-167
@@ -583,8 +583,10 @@ __device__ __forceinline__ void taylor_full(const BhwTaylorCfg &t, uint32_t cnt,
         addr = (cnt >> (pw - L - 2)) & ((1u << L) - 1u);
         f = cnt & ((1u << (pw - L - 2)) - 1u);
     }
-    const int2 sc = reinterpret_cast<const int2 *>(t.rom)[addr];
-    int64_t S = sc.x, C = sc.y, c = C, s = S;
+    const int2 sc = rom[addr];
+    const int64_t S = sc.x, C = sc.y;
+    c = C;
+    s = S;
     if (t.mode == 2) {
         const int64_t m = ((int64_t)t.pi_word * (int64_t)f) & 0xFFFFFF;              // tay1_order.vhd:133-146
         const uint32_t X = t.xshift;                                                 // :112
@@ -602,9 +604,158 @@ __device__ __forceinline__ void taylor_full(const BhwTaylorCfg &t, uint32_t cnt,
             if (s < 0) s = sat;
         }
     }
-    const int64_t nc = wrap_bits(-c, W), ns = wrap_bits(-s, W);                      // taylor_sincos.vhd:240-253
+}
+
+__device__ __forceinline__ void taylor_full(const BhwTaylorCfg &t, uint32_t cnt, int32_t &oc, int32_t &os)
+{
+    const uint32_t q = cnt >> (t.phi_width - 2);
+    int64_t s, c;
+    taylor_q1(t, reinterpret_cast<const int2 *>(t.rom), cnt, s, c);
+    const int64_t nc = wrap_bits(-c, t.dat_width), ns = wrap_bits(-s, t.dat_width);  // taylor_sincos.vhd:240-253
     oc = (int32_t)((q == 0) ? c : (q == 1) ? ns : (q == 2) ? nc : s);
     os = (int32_t)((q == 0) ? s : (q == 1) ? c : (q == 2) ? ns : nc);
+}
+
+// ---- 32-bit forms for dat_width <= 16 (every product a*v and every sum fits int32; same results) ----
+__device__ __forceinline__ int32_t wrap32(int32_t v, uint32_t bits)
+{
+    const uint32_t sh = 32u - bits;
+    return (int32_t)((uint32_t)v << sh) >> sh;
+}
+
+__device__ __forceinline__ void taylor_q1_narrow(const BhwTaylorCfg &t, const int2 *rom, uint32_t cnt, int32_t &s, int32_t &c)
+{
+    const uint32_t pw = t.phi_width, W = t.dat_width, L = t.lut_size;
+    uint32_t addr, f = 0;
+    if (t.mode == 0)      addr = (cnt & ((1u << (pw - 2)) - 1u)) << (L - pw + 2);
+    else if (t.mode == 1) addr = cnt & ((1u << L) - 1u);
+    else {
+        addr = (cnt >> (pw - L - 2)) & ((1u << L) - 1u);
+        f = cnt & ((1u << (pw - L - 2)) - 1u);
+    }
+    const int2 sc = rom[addr];
+    s = sc.x;
+    c = sc.y;
+    if (t.mode == 2) {                                       // W < 19 path: tay1_order.vhd:192-208,501-502
+        const int32_t m = (int32_t)((t.pi_word * f) & 0xFFFFFFu);
+        const uint32_t X = t.xshift;
+        // ((C << X) - m*S) >> X == C + ((-(m*S)) >> X) because C << X is a multiple of 2^X
+        const int32_t dc = (int32_t)((-((int64_t)m * sc.x)) >> X);
+        const int32_t ds = (int32_t)(((int64_t)m * sc.y) >> X);
+        c = wrap32(sc.y + dc, W);
+        s = wrap32(sc.x + ds, W);
+    }
+}
+
+__device__ __forceinline__ int32_t narrow_term(int32_t a, int32_t v, uint32_t W, uint32_t combine)
+{
+    int32_t m = (a * v) >> (W - 2);                          // |a|,|v| < 2^15: exact in int32
+    if (combine == BHW_COMBINE_VHDL) {
+        const int32_t r = wrap32(m, W + 1);
+        m = wrap32((r >> 1) + (r & 1), W);
+    }
+    return m;
+}
+
+__device__ __forceinline__ int32_t narrow_final(int32_t acc, uint32_t W, uint32_t combine, uint32_t n_terms)
+{
+    if (combine == BHW_COMBINE_VHDL) {
+        if (n_terms == 2) {
+            const int32_t S = wrap32(acc, W + 1);
+            acc = (S >> 1) + (S & 1);
+        } else {
+            const int32_t S = wrap32(acc, W + 2);
+            acc = (S >> 2) + ((S >> 1) & 1);
+        }
+    }
+    return wrap32(acc, W);
+}
+
+// Whole-period Taylor window, quadrant fold: lane r in [0, N/4) owns n = r + j*N/4.  The first generator's quadrant
+// is then simply j; the 3-term window's second generator (PHASE_WIDTH-1, bh_win_3term.vhd:221-226) sees phase
+// n mod N/2 = r + (j & 1) * N/4, i.e. quadrant (r / (N/8)) + 2*(j & 1) of its own period.  One ROM read and one
+// Taylor correction per generator serve four coefficients; the quarter-wave ROM is staged in LDS.
+constexpr int kTaylorRomLds = 4096;     // entries (32 KiB); larger ROMs are read from global memory
+
+// Each thread takes four consecutive r so that every image is written with one 16-byte store per lane (the dword-per-
+// lane store rate on MI355X is ~4.5 TB/s, the 16-byte rate ~6.9 TB/s: profiles/r01_ubench_gfx950.txt).
+template <bool NARROW>
+__global__ __launch_bounds__(kBlock) void k_taylor_window_fold(BhwTaylorCfg t, BhwWinCfg win, int32_t *__restrict__ out)
+{
+    __shared__ int2 rom_s[kTaylorRomLds];
+    const uint32_t depth = 1u << t.lut_size;
+    const bool in_lds = depth <= (uint32_t)kTaylorRomLds;
+    if (in_lds) {
+        for (uint32_t i = threadIdx.x; i < depth; i += kBlock) rom_s[i] = reinterpret_cast<const int2 *>(t.rom)[i];
+        __syncthreads();
+    }
+    const int2 *rom_g = reinterpret_cast<const int2 *>(t.rom);
+    const uint32_t E = 1u << (t.phi_width - 2);                  // a multiple of 4 (PW >= 5 is required by the caller)
+    const uint32_t r0 = (blockIdx.x * kBlock + threadIdx.x) * 4u;
+    if (r0 >= E) return;
+    const uint32_t W = t.dat_width;
+    using val_t = typename std::conditional<NARROW, int32_t, int64_t>::type;
+    auto add_term = [&](val_t &a, int32_t weight, int32_t v, uint32_t k) {
+        if constexpr (NARROW) {
+            const int32_t m = narrow_term(weight, v, W, win.combine);
+            a += (k & 1u) ? -m : m;
+        } else {
+            combine_term(a, weight, v, k, W, win.combine);
+        }
+    };
+    auto neg = [&](val_t v) -> int32_t {
+        if constexpr (NARROW) return wrap32(-(int32_t)v, W);
+        else return (int32_t)wrap_bits(-(int64_t)v, W);
+    };
+    BhwTaylorCfg t2 = t;                                         // second generator of the 3-term window
+    t2.phi_width = t.phi_width - 1;
+    {
+        const int d = (int)t2.phi_width - (int)t2.lut_size;
+        t2.mode = d < 2 ? 0u : d == 2 ? 1u : 2u;
+        t2.pi_word = t.pad[0];
+    }
+    const uint32_t half = E >> 1;                                // quarter period of the second generator
+    int32_t res[4][4];                                           // [image j][i]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t r = r0 + (uint32_t)i;
+        val_t acc[4] = {(val_t)win.aa[0], (val_t)win.aa[0], (val_t)win.aa[0], (val_t)win.aa[0]};
+        {
+            val_t s, c;
+            if constexpr (NARROW) { if (in_lds) taylor_q1_narrow(t, rom_s, r, s, c); else taylor_q1_narrow(t, rom_g, r, s, c); }
+            else                  { if (in_lds) taylor_q1(t, rom_s, r, s, c);        else taylor_q1(t, rom_g, r, s, c); }
+            const int32_t v[4] = {(int32_t)c, neg(s), neg(c), (int32_t)s};       // quadrant j: taylor_sincos.vhd:240-253
+#pragma unroll
+            for (int j = 0; j < 4; ++j) add_term(acc[j], win.aa[1], v[j], 1);
+        }
+        if (win.n_terms > 2) {
+            val_t s, c;
+            if constexpr (NARROW) { if (in_lds) taylor_q1_narrow(t2, rom_s, r & (half - 1u), s, c); else taylor_q1_narrow(t2, rom_g, r & (half - 1u), s, c); }
+            else                  { if (in_lds) taylor_q1(t2, rom_s, r & (half - 1u), s, c);        else taylor_q1(t2, rom_g, r & (half - 1u), s, c); }
+            const bool hi = r >= half;                           // quadrant 0 or 1 at j even, 2 or 3 at j odd
+            const int32_t even = hi ? neg(s) : (int32_t)c;       // quadrant 0: c, 1: -s
+            const int32_t odd = hi ? (int32_t)s : neg(c);        // quadrant 2: -c, 3: s
+            add_term(acc[0], win.aa[2], even, 2);
+            add_term(acc[1], win.aa[2], odd, 2);
+            add_term(acc[2], win.aa[2], even, 2);
+            add_term(acc[3], win.aa[2], odd, 2);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (NARROW) res[j][i] = narrow_final(acc[j], W, win.combine, win.n_terms);
+            else res[j][i] = combine_final(acc[j], W, win.combine, win.n_terms);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint64_t idx = (uint64_t)r0 + (uint64_t)j * E;
+        if (win.apply_x || (((uintptr_t)out) & 15u)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) emit(win, out, idx + i, res[j][i]);
+        } else {
+            *reinterpret_cast<int4 *>(out + idx) = make_int4(res[j][0], res[j][1], res[j][2], res[j][3]);
+        }
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void k_taylor_window(BhwTaylorCfg t, BhwWinCfg win, uint64_t n0, uint64_t count,
@@ -857,6 +1008,19 @@ int bhwk_taylor_window(const BhwLaunch &l, const BhwTaylorCfg &t, const BhwWinCf
     if (!count) return 0;
     BHW_SET_DEVICE(l);
     hipLaunchKernelGGL(k_taylor_window, dim3(grid_for(count)), dim3(kBlock), 0, (hipStream_t)l.stream, t, w, n0, count, d_out);
+    return finish(hipSuccess);
+}
+
+int bhwk_taylor_window_fold(const BhwLaunch &l, const BhwTaylorCfg &t, const BhwWinCfg &w, int32_t *d_out)
+{
+    BHW_SET_DEVICE(l);
+    const uint32_t E = 1u << (t.phi_width - 2);
+    // dat_width <= 16 with weights inside the W-bit range: every product and sum fits int32
+    bool narrow = t.dat_width <= 16;
+    for (uint32_t k = 0; k < w.n_terms; ++k) narrow = narrow && w.aa[k] < (1 << 15) && w.aa[k] >= -(1 << 15);
+    const dim3 grid(grid_for(E / 4));
+    if (narrow) hipLaunchKernelGGL(k_taylor_window_fold<true>, grid, dim3(kBlock), 0, (hipStream_t)l.stream, t, w, d_out);
+    else        hipLaunchKernelGGL(k_taylor_window_fold<false>, grid, dim3(kBlock), 0, (hipStream_t)l.stream, t, w, d_out);
     return finish(hipSuccess);
 }
 

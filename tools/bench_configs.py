@@ -56,6 +56,10 @@ def main():
         ms = timeit(lambda: bhw.generate(pn, 0, 1 << 26, out=o3, algo=B.ALGO_TABLE), iters=10, warm=2)
         res[f"narrow_bh7_2^26_{name}_table"] = {"ms": ms, "Gsamples/s": (1 << 26) / ms / 1e6, "GB/s": 4 * (1 << 26) / ms / 1e6,
                                                "table_entries": 1 << (w - 2)}
+    for name, win, w in (("hamming_16bit", 1, 16), ("bh3_24bit", 3, 24), ("hamming_32bit", 1, 32)):
+        pt = bhw.make_params(win, 26, w, sin_type=B.SIN_TAYLOR, combine=B.COMBINE_VHDL, lut_size=9)
+        ms = timeit(lambda: bhw.generate(pt, 0, 1 << 26, out=o3), iters=10, warm=2)
+        res[f"taylor_{name}_2^26"] = {"ms": ms, "Gsamples/s": (1 << 26) / ms / 1e6, "GB/s": 4 * (1 << 26) / ms / 1e6}
     pc = bhw.make_params(1, 26, 32, model=B.MODEL_CPP)
     ms = timeit(lambda: bhw.cordic(pc, 0, 1 << 26), iters=5, warm=1)
     res["sincos_cpp_2^26_32bit"] = {"ms": ms, "Gphases/s": (1 << 26) / ms / 1e6}
