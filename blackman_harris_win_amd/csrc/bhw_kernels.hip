@@ -639,9 +639,17 @@ __device__ __forceinline__ void taylor_q1_narrow(const BhwTaylorCfg &t, const in
     if (t.mode == 2) {                                       // W < 19 path: tay1_order.vhd:192-208,501-502
         const int32_t m = (int32_t)((t.pi_word * f) & 0xFFFFFFu);
         const uint32_t X = t.xshift;
-        // ((C << X) - m*S) >> X == C + ((-(m*S)) >> X) because C << X is a multiple of 2^X
-        const int32_t dc = (int32_t)((-((int64_t)m * sc.x)) >> X);
-        const int32_t ds = (int32_t)(((int64_t)m * sc.y) >> X);
+        // ((C << X) - m*S) >> X == C + ((-(m*S)) >> X) because C << X is a multiple of 2^X.  m < pi * 2^18 < 2^20, so for
+        // X <= 32 (LUT_SIZE <= 13) the floor shifts are one v_mul_hi_i32 each: (m*v) >> X == mulhi(m << (32-X), v).
+        int32_t dc, ds;
+        if (X <= 32u && L >= 2u) {
+            const int32_t ms = (int32_t)((uint32_t)m << (32u - X));
+            dc = __mulhi(ms, -sc.x);
+            ds = __mulhi(ms, sc.y);
+        } else {
+            dc = (int32_t)((-((int64_t)m * sc.x)) >> X);
+            ds = (int32_t)(((int64_t)m * sc.y) >> X);
+        }
         c = wrap32(sc.y + dc, W);
         s = wrap32(sc.x + ds, W);
     }
@@ -679,28 +687,28 @@ constexpr int kTaylorRomLds = 4096;     // entries (32 KiB); larger ROMs are rea
 
 // Each thread takes four consecutive r so that every image is written with one 16-byte store per lane (the dword-per-
 // lane store rate on MI355X is ~4.5 TB/s, the 16-byte rate ~6.9 TB/s: profiles/r01_ubench_gfx950.txt).
-template <bool NARROW>
+// FAST: both generators take the 1st-order-correction path (PHASE_WIDTH - LUT_SIZE > 3) and the ROM fits LDS -- the usual case.
+template <bool NARROW, uint32_t COMBINE, uint32_t NTERMS, bool FAST>
 __global__ __launch_bounds__(kBlock) void k_taylor_window_fold(BhwTaylorCfg t, BhwWinCfg win, int32_t *__restrict__ out)
 {
     __shared__ int2 rom_s[kTaylorRomLds];
     const uint32_t depth = 1u << t.lut_size;
-    const bool in_lds = depth <= (uint32_t)kTaylorRomLds;
+    const bool in_lds = FAST || depth <= (uint32_t)kTaylorRomLds;
+    if constexpr (FAST) { t.mode = 2u; }
     if (in_lds) {
         for (uint32_t i = threadIdx.x; i < depth; i += kBlock) rom_s[i] = reinterpret_cast<const int2 *>(t.rom)[i];
         __syncthreads();
     }
     const int2 *rom_g = reinterpret_cast<const int2 *>(t.rom);
     const uint32_t E = 1u << (t.phi_width - 2);                  // a multiple of 4 (PW >= 5 is required by the caller)
-    const uint32_t r0 = (blockIdx.x * kBlock + threadIdx.x) * 4u;
-    if (r0 >= E) return;
     const uint32_t W = t.dat_width;
     using val_t = typename std::conditional<NARROW, int32_t, int64_t>::type;
     auto add_term = [&](val_t &a, int32_t weight, int32_t v, uint32_t k) {
         if constexpr (NARROW) {
-            const int32_t m = narrow_term(weight, v, W, win.combine);
+            const int32_t m = narrow_term(weight, v, W, COMBINE);
             a += (k & 1u) ? -m : m;
         } else {
-            combine_term(a, weight, v, k, W, win.combine);
+            combine_term(a, weight, v, k, W, COMBINE);
         }
     };
     auto neg = [&](val_t v) -> int32_t {
@@ -711,10 +719,12 @@ __global__ __launch_bounds__(kBlock) void k_taylor_window_fold(BhwTaylorCfg t, B
     t2.phi_width = t.phi_width - 1;
     {
         const int d = (int)t2.phi_width - (int)t2.lut_size;
-        t2.mode = d < 2 ? 0u : d == 2 ? 1u : 2u;
+        t2.mode = FAST ? 2u : (d < 2 ? 0u : d == 2 ? 1u : 2u);
         t2.pi_word = t.pad[0];
     }
     const uint32_t half = E >> 1;                                // quarter period of the second generator
+    // grid-stride over 1024-coefficient-wide chunks of r: the ROM staging above is paid once per workgroup
+    for (uint32_t r0 = (blockIdx.x * kBlock + threadIdx.x) * 4u; r0 < E; r0 += gridDim.x * kBlock * 4u) {
     int32_t res[4][4];                                           // [image j][i]
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -728,7 +738,7 @@ __global__ __launch_bounds__(kBlock) void k_taylor_window_fold(BhwTaylorCfg t, B
 #pragma unroll
             for (int j = 0; j < 4; ++j) add_term(acc[j], win.aa[1], v[j], 1);
         }
-        if (win.n_terms > 2) {
+        if constexpr (NTERMS > 2) {
             val_t s, c;
             if constexpr (NARROW) { if (in_lds) taylor_q1_narrow(t2, rom_s, r & (half - 1u), s, c); else taylor_q1_narrow(t2, rom_g, r & (half - 1u), s, c); }
             else                  { if (in_lds) taylor_q1(t2, rom_s, r & (half - 1u), s, c);        else taylor_q1(t2, rom_g, r & (half - 1u), s, c); }
@@ -742,8 +752,8 @@ __global__ __launch_bounds__(kBlock) void k_taylor_window_fold(BhwTaylorCfg t, B
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if constexpr (NARROW) res[j][i] = narrow_final(acc[j], W, win.combine, win.n_terms);
-            else res[j][i] = combine_final(acc[j], W, win.combine, win.n_terms);
+            if constexpr (NARROW) res[j][i] = narrow_final(acc[j], W, COMBINE, NTERMS);
+            else res[j][i] = combine_final(acc[j], W, COMBINE, NTERMS);
         }
     }
 #pragma unroll
@@ -755,6 +765,7 @@ __global__ __launch_bounds__(kBlock) void k_taylor_window_fold(BhwTaylorCfg t, B
         } else {
             *reinterpret_cast<int4 *>(out + idx) = make_int4(res[j][0], res[j][1], res[j][2], res[j][3]);
         }
+    }
     }
 }
 
@@ -1018,9 +1029,29 @@ int bhwk_taylor_window_fold(const BhwLaunch &l, const BhwTaylorCfg &t, const Bhw
     // dat_width <= 16 with weights inside the W-bit range: every product and sum fits int32
     bool narrow = t.dat_width <= 16;
     for (uint32_t k = 0; k < w.n_terms; ++k) narrow = narrow && w.aa[k] < (1 << 15) && w.aa[k] >= -(1 << 15);
-    const dim3 grid(grid_for(E / 4));
-    if (narrow) hipLaunchKernelGGL(k_taylor_window_fold<true>, grid, dim3(kBlock), 0, (hipStream_t)l.stream, t, w, d_out);
-    else        hipLaunchKernelGGL(k_taylor_window_fold<false>, grid, dim3(kBlock), 0, (hipStream_t)l.stream, t, w, d_out);
+    unsigned blocks = grid_for(E / 4);
+#ifndef BHW_TAYLOR_BLOCKS
+#define BHW_TAYLOR_BLOCKS 4096u
+#endif
+    if (blocks > BHW_TAYLOR_BLOCKS) blocks = BHW_TAYLOR_BLOCKS;
+    const dim3 grid(blocks);
+    hipStream_t st = (hipStream_t)l.stream;
+#define BHW_TAYLOR_FOLD(NARROW, COMBINE, NT)                                                                        \
+    do {                                                                                                            \
+        if (fast) hipLaunchKernelGGL((k_taylor_window_fold<NARROW, COMBINE, NT, true>), grid, dim3(kBlock), 0, st, t, w, d_out);  \
+        else      hipLaunchKernelGGL((k_taylor_window_fold<NARROW, COMBINE, NT, false>), grid, dim3(kBlock), 0, st, t, w, d_out); \
+    } while (0)
+    const bool vhdl = w.combine == BHW_COMBINE_VHDL, three = w.n_terms > 2;
+    const bool fast = (1u << t.lut_size) <= (uint32_t)kTaylorRomLds && t.mode == 2u &&
+                      (!three || (int)t.phi_width - 1 - (int)t.lut_size > 2);
+    if (narrow) {
+        if (vhdl) { if (three) BHW_TAYLOR_FOLD(true, BHW_COMBINE_VHDL, 3); else BHW_TAYLOR_FOLD(true, BHW_COMBINE_VHDL, 2); }
+        else      { if (three) BHW_TAYLOR_FOLD(true, BHW_COMBINE_HLS, 3);  else BHW_TAYLOR_FOLD(true, BHW_COMBINE_HLS, 2); }
+    } else {
+        if (vhdl) { if (three) BHW_TAYLOR_FOLD(false, BHW_COMBINE_VHDL, 3); else BHW_TAYLOR_FOLD(false, BHW_COMBINE_VHDL, 2); }
+        else      { if (three) BHW_TAYLOR_FOLD(false, BHW_COMBINE_HLS, 3);  else BHW_TAYLOR_FOLD(false, BHW_COMBINE_HLS, 2); }
+    }
+#undef BHW_TAYLOR_FOLD
     return finish(hipSuccess);
 }
 
