@@ -291,9 +291,17 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
         rc = ensure_scratch(device, stream, need, &ws);
         if (rc) return rc;
     }
+    // Split the range into  head | whole periods | tail  : the whole periods take the fold / tile kernels (and store-only
+    // replication), the ragged ends the general gather kernel -- all over the one table built here.
     const uint64_t N = 1ull << p->phi_width;
-    const bool whole = (n0 % N == 0 && count % N == 0);
-    const bool tiled = whole && bhwk_tile_applicable(c, w);
+    const uint64_t head_len = (N - n0 % N) % N;
+    uint64_t head = 0, periods = 0, tail = count;
+    if (count >= head_len + N) {
+        head = head_len;
+        periods = (count - head) / N;
+        tail = count - head - periods * N;
+    }
+    const bool tiled = periods > 0 && bhwk_tile_applicable(c, w);
     c.tab_split = (tiled && c.z_shr == 0) ? 1u : 0u;
     int e = bhwk_table_build(l, c, (int32_t *)ws);
     if (e) return fail_hip(e, "table build launch");
@@ -301,25 +309,34 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
         hipError_t he = hipEventRecord((hipEvent_t)ex->event_after_build, (hipStream_t)stream);
         if (he != hipSuccess) return fail_hip(he, "hipEventRecord(event_after_build)");
     }
-    if (whole) {
-        // whole periods: quadrant-fold combine for the first, store-only replication for the rest; with the fused
-        // apply every period has its own x, so the combine pass runs once per period on the one table
-        const uint64_t periods = apply_x ? count / N : 1;
-        for (uint64_t f = 0; f < periods; ++f) {
-            if (apply_x) w.apply_x = apply_x + f * N;
-            int32_t *o = d_out + f * N;
-            e = tiled ? bhwk_table_combine_tile(l, c, w, (const int32_t *)ws, o)
-                      : bhwk_table_combine_fold(l, c, w, (const int32_t *)ws, o);
-            if (e) return fail_hip(e, "table combine (fold) launch");
-        }
-        if (!apply_x && count > N) {
-            e = bhwk_replicate(l, d_out, N, (uint32_t)(count / N - 1), d_out + N);
-            if (e) return fail_hip(e, "replicate launch");
-        }
-        return BHW_OK;
+    const int32_t *x0 = apply_x;
+    auto ragged = [&](uint64_t off, uint64_t len) -> int {
+        if (!len) return 0;
+        if (x0) w.apply_x = x0 + off;
+        return bhwk_table_combine(l, c, w, (const int32_t *)ws, n0 + off, len, d_out + off);
+    };
+    if (periods == 0) {
+        e = ragged(0, count);
+        return e ? fail_hip(e, "table combine launch") : BHW_OK;
     }
-    e = bhwk_table_combine(l, c, w, (const int32_t *)ws, n0, count, d_out);
-    return e ? fail_hip(e, "table combine launch") : BHW_OK;
+    e = ragged(0, head);
+    if (e) return fail_hip(e, "table combine (head) launch");
+    // with the fused apply every period has its own x, so the combine pass runs once per period; otherwise the first
+    // period is computed and the rest are store-only replicas
+    const uint64_t computed = x0 ? periods : 1;
+    for (uint64_t f = 0; f < computed; ++f) {
+        if (x0) w.apply_x = x0 + head + f * N;
+        int32_t *o = d_out + head + f * N;
+        e = tiled ? bhwk_table_combine_tile(l, c, w, (const int32_t *)ws, o)
+                  : bhwk_table_combine_fold(l, c, w, (const int32_t *)ws, o);
+        if (e) return fail_hip(e, "table combine (fold) launch");
+    }
+    if (!x0 && periods > 1) {
+        e = bhwk_replicate(l, d_out + head, N, (uint32_t)(periods - 1), d_out + head + N);
+        if (e) return fail_hip(e, "replicate launch");
+    }
+    e = ragged(head + periods * N, tail);
+    return e ? fail_hip(e, "table combine (tail) launch") : BHW_OK;
 }
 
 } // namespace

@@ -153,6 +153,12 @@ class WinSelector:
         self._phase = (self._phase + int(count)) % self.length
         return w
 
+    def apply(self, x, shift=None, out=None):
+        """The multiplier stage behind DT_WIN for the next x.numel() clocks: y = (x * DT_WIN) >> shift."""
+        y = apply(self.params, x, n0=self._phase, shift=shift, out=out)
+        self._phase = (self._phase + x.numel()) % self.length
+        return y
+
     def window(self, out=None, algo=B.ALGO_AUTO):
         """One full period from phase 0."""
         return generate(self.params, 0, self.length, device=self.device, out=out, algo=algo)

@@ -79,6 +79,12 @@ public:
         phase_ = (phase_ + count) % length();
         return v;
     }
+    // the multiplier stage behind DT_WIN: d_y[i] = (d_x[i] * DT_WIN) >> shift for the next `count` clocks
+    void APPLY(uint64_t count, const int32_t *d_x, int32_t *d_y, unsigned shift, void *stream = nullptr)
+    {
+        check(bhw_apply_device(&p_, device_, stream, phase_, count, d_x, d_y, shift));
+        phase_ = (phase_ + count) % length();
+    }
     const bhw_params &params() const { return p_; }
 
 private:

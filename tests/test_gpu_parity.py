@@ -191,6 +191,18 @@ def test_ragged_counts_and_offsets(torch, algo):
         assert np.array_equal(gpu_generate(p, n0, count, algo), O.generate(po, n0, count)), (n0, count)
 
 
+@pytest.mark.parametrize("win,pw,w,model,n0,count", [
+    (7, 12, 32, B.MODEL_HLS, 1000, 3 * 4096 + 123),            # head + 2 periods (fold + replicate) + tail
+    (4, 10, 24, B.MODEL_CPP, 1023, 1025),                       # 1-sample head, one period, no tail
+    (5, 11, 16, B.MODEL_VHDL, 2048 * 7 + 1, 2047 + 2048),       # head + exactly one period
+    (7, 20, 32, B.MODEL_HLS, 12345, (1 << 20) + (1 << 19)),     # tile kernel in the middle of a ragged range
+])
+def test_ragged_range_spanning_whole_periods(torch, win, pw, w, model, n0, count):
+    p = B.make_params(win, pw, w, model=model)
+    want = O.generate(O.from_bhw(p), n0, count)
+    assert np.array_equal(gpu_generate(p, n0, count, B.ALGO_TABLE), want)
+
+
 def test_empty_and_null_arguments(torch):
     L = B.lib()
     p = B.make_params(4, 12, 24)
@@ -277,6 +289,13 @@ def test_win_selector_streaming_counter(torch):
     assert np.array_equal(b, np.concatenate([full[700:], full[:376]]))
     sel.reset()
     assert np.array_equal(sel.window().cpu().numpy(), full)
+    x = torch.arange(-500, 524, dtype=torch.int32, device="cuda") * 1000003
+    sel.reset()
+    sel.enable(100)
+    y = sel.apply(x, shift=23).cpu().numpy()                   # continues from phase 100 and wraps
+    wv = np.concatenate([full[100:], full[:100]]).astype(np.int64)
+    assert np.array_equal(y, ((x.cpu().numpy().astype(np.int64) * wv) >> 23).astype(np.int32))
+    sel.reset()
     s0 = sel.shard(0, 2).cpu().numpy()
     s1 = sel.shard(1, 2).cpu().numpy()
     assert np.array_equal(np.concatenate([s0, s1]), full)
