@@ -237,6 +237,35 @@ uint32_t pick_algo(const bhw_params *p, const BhwCordicCfg &c, uint64_t count, u
     return chains_direct >= 2 * table_entries(c) ? BHW_ALGO_TABLE : BHW_ALGO_DIRECT;
 }
 
+// Runs [n0, n0+count) as  head | whole periods | tail.  `ragged(off, len)` handles an arbitrary sub-range,
+// `period(off)` one whole period starting at a multiple of N.  Without the fused apply only the first period is
+// computed and the others are store-only replicas; with it every period has its own x.
+template <typename Ragged, typename Period>
+int run_split(const BhwLaunch &l, uint64_t n0, uint64_t count, uint64_t N, bool per_period_input, int32_t *d_out,
+              Ragged ragged, Period period)
+{
+    const uint64_t head_len = (N - n0 % N) % N;
+    int e;
+    if (count < head_len + N) {
+        e = ragged(0, count);
+        return e ? fail_hip(e, "launch") : BHW_OK;
+    }
+    const uint64_t head = head_len, periods = (count - head) / N, tail = count - head - periods * N;
+    e = head ? ragged(0, head) : 0;
+    if (e) return fail_hip(e, "head launch");
+    const uint64_t computed = per_period_input ? periods : 1;
+    for (uint64_t f = 0; f < computed; ++f) {
+        e = period(head + f * N);
+        if (e) return fail_hip(e, "whole-period launch");
+    }
+    if (!per_period_input && periods > 1) {
+        e = bhwk_replicate(l, d_out + head, N, (uint32_t)(periods - 1), d_out + head + N);
+        if (e) return fail_hip(e, "replicate launch");
+    }
+    e = tail ? ragged(head + periods * N, tail) : 0;
+    return e ? fail_hip(e, "tail launch") : BHW_OK;
+}
+
 int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, uint64_t count, int32_t *d_out,
                   const bhw_exec *ex, const int32_t *apply_x = nullptr, uint32_t apply_shift = 0)
 {
@@ -245,6 +274,7 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
     if (count && !d_out) return fail(BHW_ERR_BADARG, "d_out is NULL");
     if (ex && ex->struct_size != sizeof(bhw_exec)) return fail(BHW_ERR_BADARG, "bhw_exec.struct_size");
     if (!count) return BHW_OK;
+    if (count > (1ull << 34)) return fail(BHW_ERR_BADARG, "count %llu > 2^34 per call", (unsigned long long)count);
     if (!device_ok(device)) return fail(BHW_ERR_HIP, "no usable HIP device %d (this library has no CPU path)", device);
     BhwLaunch l{device, stream};
     BhwWinCfg w;
@@ -256,22 +286,19 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
         rc = resolve_taylor(p, device, stream, t);
         if (rc) return rc;
         const uint64_t NT = 1ull << p->phi_width;
-        if (p->phi_width >= 5 && n0 % NT == 0 && count % NT == 0) {
-            // whole periods: quadrant-fold kernel per period (fused apply) or once + store-only replication
-            const uint64_t periods = apply_x ? count / NT : 1;
-            for (uint64_t f = 0; f < periods; ++f) {
-                if (apply_x) w.apply_x = apply_x + f * NT;
-                int e = bhwk_taylor_window_fold(l, t, w, d_out + f * NT);
-                if (e) return fail_hip(e, "taylor window (fold) launch");
-            }
-            if (!apply_x && count > NT) {
-                int e = bhwk_replicate(l, d_out, NT, (uint32_t)(count / NT - 1), d_out + NT);
-                if (e) return fail_hip(e, "replicate launch");
-            }
-            return BHW_OK;
+        auto ragged = [&](uint64_t off, uint64_t len) -> int {
+            if (apply_x) w.apply_x = apply_x + off;
+            return bhwk_taylor_window(l, t, w, n0 + off, len, d_out + off);
+        };
+        if (p->phi_width < 5) {
+            int e = ragged(0, count);
+            return e ? fail_hip(e, "taylor window launch") : BHW_OK;
         }
-        int e = bhwk_taylor_window(l, t, w, n0, count, d_out);
-        return e ? fail_hip(e, "taylor window launch") : BHW_OK;
+        auto period = [&](uint64_t off) -> int {
+            if (apply_x) w.apply_x = apply_x + off;
+            return bhwk_taylor_window_fold(l, t, w, d_out + off);
+        };
+        return run_split(l, n0, count, NT, apply_x != nullptr, d_out, ragged, period);
     }
     BhwCordicCfg c;
     resolve_cordic(p, c);
@@ -291,17 +318,11 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
         rc = ensure_scratch(device, stream, need, &ws);
         if (rc) return rc;
     }
-    // Split the range into  head | whole periods | tail  : the whole periods take the fold / tile kernels (and store-only
-    // replication), the ragged ends the general gather kernel -- all over the one table built here.
+    // head | whole periods | tail over the one table built here: the whole periods take the fold / tile kernels, the
+    // ragged ends the general gather kernel
     const uint64_t N = 1ull << p->phi_width;
-    const uint64_t head_len = (N - n0 % N) % N;
-    uint64_t head = 0, periods = 0, tail = count;
-    if (count >= head_len + N) {
-        head = head_len;
-        periods = (count - head) / N;
-        tail = count - head - periods * N;
-    }
-    const bool tiled = periods > 0 && bhwk_tile_applicable(c, w);
+    const bool has_period = count >= (N - n0 % N) % N + N;
+    const bool tiled = has_period && bhwk_tile_applicable(c, w);
     c.tab_split = (tiled && c.z_shr == 0) ? 1u : 0u;
     int e = bhwk_table_build(l, c, (int32_t *)ws);
     if (e) return fail_hip(e, "table build launch");
@@ -309,34 +330,16 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
         hipError_t he = hipEventRecord((hipEvent_t)ex->event_after_build, (hipStream_t)stream);
         if (he != hipSuccess) return fail_hip(he, "hipEventRecord(event_after_build)");
     }
-    const int32_t *x0 = apply_x;
     auto ragged = [&](uint64_t off, uint64_t len) -> int {
-        if (!len) return 0;
-        if (x0) w.apply_x = x0 + off;
+        if (apply_x) w.apply_x = apply_x + off;
         return bhwk_table_combine(l, c, w, (const int32_t *)ws, n0 + off, len, d_out + off);
     };
-    if (periods == 0) {
-        e = ragged(0, count);
-        return e ? fail_hip(e, "table combine launch") : BHW_OK;
-    }
-    e = ragged(0, head);
-    if (e) return fail_hip(e, "table combine (head) launch");
-    // with the fused apply every period has its own x, so the combine pass runs once per period; otherwise the first
-    // period is computed and the rest are store-only replicas
-    const uint64_t computed = x0 ? periods : 1;
-    for (uint64_t f = 0; f < computed; ++f) {
-        if (x0) w.apply_x = x0 + head + f * N;
-        int32_t *o = d_out + head + f * N;
-        e = tiled ? bhwk_table_combine_tile(l, c, w, (const int32_t *)ws, o)
-                  : bhwk_table_combine_fold(l, c, w, (const int32_t *)ws, o);
-        if (e) return fail_hip(e, "table combine (fold) launch");
-    }
-    if (!x0 && periods > 1) {
-        e = bhwk_replicate(l, d_out + head, N, (uint32_t)(periods - 1), d_out + head + N);
-        if (e) return fail_hip(e, "replicate launch");
-    }
-    e = ragged(head + periods * N, tail);
-    return e ? fail_hip(e, "table combine (tail) launch") : BHW_OK;
+    auto period = [&](uint64_t off) -> int {
+        if (apply_x) w.apply_x = apply_x + off;
+        return tiled ? bhwk_table_combine_tile(l, c, w, (const int32_t *)ws, d_out + off)
+                     : bhwk_table_combine_fold(l, c, w, (const int32_t *)ws, d_out + off);
+    };
+    return run_split(l, n0, count, N, apply_x != nullptr, d_out, ragged, period);
 }
 
 } // namespace
