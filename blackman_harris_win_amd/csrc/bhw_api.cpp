@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -324,7 +325,16 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
     const bool has_period = count >= (N - n0 % N) % N + N;
     const bool tiled = has_period && bhwk_tile_applicable(c, w);
     c.tab_split = (tiled && c.z_shr == 0) ? 1u : 0u;
-    int e = bhwk_table_build(l, c, (int32_t *)ws);
+    // large whole-period tables are stored residual-compressed (2 bytes per entry + one exact record per 2^d entries);
+    // both live inside the same scratch: [ residual table, E * 2 B | ... | coarse records at byte offset E * 4 ]
+    // (measured on MI355X: 4x less table traffic but +9 % time -- the combine pass is bound by L1 line accesses of its
+    // strided gathers, not by bytes -- so it is off unless BHW_TABLE_COMPRESS=1 is set in the environment)
+    static const bool compress = [] { const char *e = getenv("BHW_TABLE_COMPRESS"); return e && e[0] == '1'; }();
+    c.tab_dlog = (tiled && compress) ? bhwk_comp_dlog(c) : 0u;
+    c.tab_coarse = c.tab_dlog ? (const void *)((const char *)ws + table_entries(c) * 4ull) : nullptr;
+    int e = bhwk_coarse_build(l, c);
+    if (e) return fail_hip(e, "coarse table launch");
+    e = bhwk_table_build(l, c, (int32_t *)ws);
     if (e) return fail_hip(e, "table build launch");
     if (ex && ex->event_after_build) {
         hipError_t he = hipEventRecord((hipEvent_t)ex->event_after_build, (hipStream_t)stream);

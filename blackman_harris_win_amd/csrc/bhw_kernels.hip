@@ -77,6 +77,42 @@ __device__ __forceinline__ uint32_t tab_index(uint32_t u, uint32_t log2_entries,
     return (u & 1u) ? (e >> 1) + (u >> 1) : (u & 2u) ? (e >> 2) + (u >> 2) : (u >> 2);
 }
 
+// Residual-compressed table (cfg.tab_dlog = d > 0, z_shr == 0 only).  (c, s)(t) is smooth in t: between two exact
+// records 2^d entries apart it deviates from the straight line through them by the CORDIC's own rounding noise
+// (a few LSB) plus < 1 LSB of curvature (d is chosen for that, bhwk_comp_dlog).  The table stores that deviation in
+// one byte per component -- 2 bytes per entry instead of 8 -- and both passes evaluate the same integer predictor
+//   pred(t) = rec.c + ((rec.dc * (t mod 2^d)) >> d)          rec = coarse[t >> d] = {c, s, dc, ds}
+// so the reconstruction is exact.  |deviation| <= ~30 for every width (<= 32 rotations of < 1 LSB each, twice), far
+// inside int8.
+__device__ __forceinline__ int2 tab_predict(const int4 rec, uint32_t f, uint32_t d)
+{
+    return make_int2(rec.x + ((rec.z * (int32_t)f) >> d), rec.y + ((rec.w * (int32_t)f) >> d));
+}
+
+__device__ __forceinline__ int2 tab_load(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t log2_entries)
+{
+    const uint32_t idx = tab_index(u, log2_entries, cfg.tab_split);
+    const uint32_t d = cfg.tab_dlog;
+    if (d == 0) return reinterpret_cast<const int2 *>(table)[idx];
+    const uint32_t r = reinterpret_cast<const uint16_t *>(table)[idx];
+    const int4 rec = reinterpret_cast<const int4 *>(cfg.tab_coarse)[u >> d];
+    const int2 p = tab_predict(rec, u & ((1u << d) - 1u), d);
+    return make_int2(p.x + (int32_t)(int8_t)(r & 0xFFu), p.y + (int32_t)(int8_t)(r >> 8));
+}
+
+__device__ __forceinline__ void tab_store(void *__restrict__ table, uint32_t u, uint32_t log2_entries, uint32_t split, uint32_t d,
+                                          const void *coarse, int32_t c, int32_t s)
+{
+    const uint32_t idx = tab_index(u, log2_entries, split);
+    if (d == 0) {
+        reinterpret_cast<int2 *>(table)[idx] = make_int2(c, s);
+        return;
+    }
+    const int4 rec = reinterpret_cast<const int4 *>(coarse)[u >> d];
+    const int2 p = tab_predict(rec, u & ((1u << d) - 1u), d);
+    reinterpret_cast<uint16_t *>(table)[idx] = (uint16_t)(((uint32_t)(c - p.x) & 0xFFu) | (((uint32_t)(s - p.y) & 0xFFu) << 8));
+}
+
 // Accumulate one harmonic.  HLS rule: hls/windows/win_function.cpp:368-375;
 // VHDL rule: src/bh_win_7term.vhd:353-402 (slice, round) -- SURVEY App. A.4/A.6.
 __device__ __forceinline__ void combine_term(int64_t &acc, int32_t a, int32_t cosv, uint32_t k, uint32_t W, uint32_t combine)
@@ -167,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void k_sincos(BhwCordicCfg cfg, uint64_t th
 // applied after the rotation), so the whole window needs only 2^(PW-2-z_shr) chains.
 // ---------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_table_build(BhwCordicCfg cfg, uint32_t entries, int2 *__restrict__ table)
+__global__ __launch_bounds__(kBlock) void k_table_build(BhwCordicCfg cfg, uint32_t entries, void *__restrict__ table)
 {
     __shared__ T lut_s[32];
     stage_lut<T>(cfg, lut_s);
@@ -175,7 +211,8 @@ __global__ __launch_bounds__(kBlock) void k_table_build(BhwCordicCfg cfg, uint32
     if (u >= entries) return;
     T x, y;
     cordic_q1<T>(lut_s, (T)cfg.x0, (T)((T)u << cfg.z_shl), (int)cfg.n_iter, x, y);
-    table[tab_index(u, cfg.phi_width - 2 - cfg.z_shr, cfg.tab_split)] = make_int2((int32_t)(x >> cfg.out_shr), (int32_t)(y >> cfg.out_shr));
+    tab_store(table, u, cfg.phi_width - 2 - cfg.z_shr, cfg.tab_split, cfg.tab_dlog, cfg.tab_coarse,
+              (int32_t)(x >> cfg.out_shr), (int32_t)(y >> cfg.out_shr));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -206,6 +243,9 @@ struct BhwBuildPlan {
     uint32_t out_shr;
     uint32_t log2_entries;
     uint32_t tab_split;
+    uint32_t tab_dlog;        // residual compression (see tab_load)
+    uint32_t pad0;
+    const void *tab_coarse;
     uint32_t groups_per_wg;   // 4, 16 or 64: small tables use small workgroups so the grid still fills the chip
     uint32_t pad;
     int64_t  x0;
@@ -230,7 +270,7 @@ __device__ __forceinline__ void rot_step(int64_t &x, int64_t &y, int32_t &z, int
 }
 
 template <int NITER>
-__global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPlan plan, int2 *__restrict__ table)
+__global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPlan plan, void *__restrict__ table)
 {
     __shared__ int64_t gx[kGroupsPerWg];
     __shared__ int64_t gy[kGroupsPerWg];
@@ -288,8 +328,36 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
         for (int k = 1; k < NITER; ++k) {
             if (k >= k0) rot_step(x, y, z, k, plan.lut[k]);
         }
-        table[tab_index((g << 6) + lane, plan.log2_entries, plan.tab_split)] = make_int2((int32_t)(x >> plan.out_shr), (int32_t)(y >> plan.out_shr));
+        tab_store(table, (g << 6) + lane, plan.log2_entries, plan.tab_split, plan.tab_dlog, plan.tab_coarse,
+                  (int32_t)(x >> plan.out_shr), (int32_t)(y >> plan.out_shr));
     }
+}
+
+// Coarse records of the residual-compressed table: thread i evaluates the full chain (no sharing; E >> d of them) at
+// t = i*2^d and at the next grid point, and stores {c, s, dc, ds}.  The last cell has no next point inside the
+// quadrant and reuses the slope of the cell before it (its curvature error stays far inside the residual byte).
+template <int NITER>
+__global__ __launch_bounds__(kBlock) void k_coarse_build(BhwBuildPlan plan, int4 *__restrict__ coarse)
+{
+    const uint32_t d = plan.tab_dlog;
+    const uint32_t cells = plan.entries >> d;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= cells) return;
+    const bool last = (i + 1 == cells);
+    const uint32_t ua = (last ? i - 1 : i) << d, ub = ua + (1u << d);
+    int32_t cc[2], ss[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const uint32_t u = e ? ub : ua;
+        int64_t x = plan.x0, y = plan.x0;
+        int32_t z = (int32_t)((u << plan.z_shl) - plan.lut[0]);
+#pragma unroll
+        for (int r = 1; r < NITER; ++r) rot_step(x, y, z, r, plan.lut[r]);
+        cc[e] = (int32_t)(x >> plan.out_shr);
+        ss[e] = (int32_t)(y >> plan.out_shr);
+    }
+    const int32_t dc = cc[1] - cc[0], ds = ss[1] - ss[0];
+    coarse[i] = last ? make_int4(cc[1], ss[1], dc, ds) : make_int4(cc[0], ss[0], dc, ds);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -350,7 +418,7 @@ __global__ __launch_bounds__(kBlock) void k_sincos_fast(BhwCordicCfg cfg, uint64
 }
 
 // Table strategy, pass 2 (general form): one lane per coefficient, K-1 gathers.
-__global__ __launch_bounds__(kBlock) void k_table_combine(BhwCordicCfg cfg, BhwWinCfg win, const int2 *__restrict__ table,
+__global__ __launch_bounds__(kBlock) void k_table_combine(BhwCordicCfg cfg, BhwWinCfg win, const void *__restrict__ table,
                                                            uint64_t n0, uint64_t count, int32_t *__restrict__ out)
 {
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -362,7 +430,7 @@ __global__ __launch_bounds__(kBlock) void k_table_combine(BhwCordicCfg cfg, BhwW
     int64_t acc = win.aa[0];
     for (uint32_t k = 1; k < win.n_terms; ++k) {
         const uint32_t theta = (k * n) & mask;
-        const int2 cs = table[tab_index((theta & tmask) >> cfg.z_shr, pw - 2 - cfg.z_shr, cfg.tab_split)];
+        const int2 cs = tab_load(cfg, table, (theta & tmask) >> cfg.z_shr, pw - 2 - cfg.z_shr);
         int32_t c, s;
         quadrant_map(theta >> (pw - 2), cs.x, cs.y, cfg.ones_neg, c, s);
         combine_term(acc, win.aa[k], c, k, cfg.dat_width, win.combine);
@@ -374,7 +442,7 @@ __global__ __launch_bounds__(kBlock) void k_table_combine(BhwCordicCfg cfg, BhwW
 // coefficients n = r + j*N/4.  For harmonic k their phases k*n = k*r + j*k*N/4 differ only in the
 // quadrant field, which every model applies AFTER the rotation (win_function.cpp:86-88,135-150 |
 // cordic_sincos.cpp:25,70-86 | cordic_dds.vhd:170-172,232-246), so one (c, s) gather serves all four.
-__global__ __launch_bounds__(kBlock) void k_table_combine_fold(BhwCordicCfg cfg, BhwWinCfg win, const int2 *__restrict__ table,
+__global__ __launch_bounds__(kBlock) void k_table_combine_fold(BhwCordicCfg cfg, BhwWinCfg win, const void *__restrict__ table,
                                                                 int32_t *__restrict__ out)
 {
     const uint32_t pw = cfg.phi_width;
@@ -388,7 +456,7 @@ __global__ __launch_bounds__(kBlock) void k_table_combine_fold(BhwCordicCfg cfg,
     for (uint32_t k = 1; k < win.n_terms; ++k) {
         const uint32_t theta = (k * r) & mask;
         const uint32_t q = theta >> (pw - 2);
-        const int2 cs = table[tab_index((theta & tmask) >> cfg.z_shr, pw - 2 - cfg.z_shr, cfg.tab_split)];
+        const int2 cs = tab_load(cfg, table, (theta & tmask) >> cfg.z_shr, pw - 2 - cfg.z_shr);
         const int32_t nc = cfg.ones_neg ? ~cs.x : -cs.x;
         const int32_t ns = cfg.ones_neg ? ~cs.y : -cs.y;
         // cosine in quadrant 0..3: c, -s, -c, s
@@ -482,7 +550,7 @@ __device__ __forceinline__ void tile_harmonic(const BhwCordicCfg &cfg, const int
 // entry t + E/2, another dense span of the same tile.
 template <int NB, int MODE>
 __global__ __launch_bounds__(kTileThreads) void k_table_combine_tile(BhwCordicCfg cfg, BhwWinCfg win, BhwTilePlan tp,
-                                                                      const int2 *__restrict__ table, int32_t *__restrict__ out)
+                                                                      const void *__restrict__ table, int32_t *__restrict__ out)
 {
     using acc_t = typename std::conditional<MODE == 2, int64_t, int32_t>::type;
     const uint32_t lq = cfg.phi_width - 2;
@@ -512,7 +580,7 @@ __global__ __launch_bounds__(kTileThreads) void k_table_combine_tile(BhwCordicCf
             const uint32_t r = (rbase + offs[b]) & hmask;                                             \
             _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                             \
                 const uint32_t theta = ((uint32_t)K * (r + (uint32_t)g * H)) & mask;                     \
-                cs[b][g] = table[tab_index((theta & emask) >> cfg.z_shr, lq - cfg.z_shr, cfg.tab_split)]; \
+                cs[b][g] = tab_load(cfg, table, (theta & emask) >> cfg.z_shr, lq - cfg.z_shr);           \
             }                                                                                            \
         }                                                                                                \
         _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
@@ -890,6 +958,58 @@ int bhwk_replicate(const BhwLaunch &l, const int32_t *d_frame, uint64_t frame_le
     return finish(hipSuccess);
 }
 
+// Largest d <= 9 for which the straight line between records 2^d entries apart stays within half an LSB of the true
+// curve: (2 pi 2^d / 2^PW)^2 / 8 * 2^(W-2) <= 0.5.  0 = compression not applicable.
+uint32_t bhwk_comp_dlog(const BhwCordicCfg &c)
+{
+    if (c.z_shr != 0 || c.phi_width < 20 || c.dat_width + c.out_shr > 34) return 0;
+    const int amp_bits = (int)c.dat_width - 2;                       // |c|, |s| <= 2^(W-2) (+1)
+    const int twice_d = 2 * (int)c.phi_width - amp_bits - 4;         // 4.93 * 2^(2d - 2PW + W - 2) <= 0.5
+    int d = twice_d / 2;
+    if (d > 9) d = 9;
+    if (d < 6) return 0;                                             // a 64-leaf build group must sit inside one cell
+    if ((int)c.phi_width - 2 - d < 2) return 0;
+    return (uint32_t)d;
+}
+
+static void fill_build_plan(const BhwCordicCfg &c, BhwBuildPlan &plan)
+{
+    for (uint32_t k = 0; k < 32; ++k) plan.lut[k] = (uint32_t)c.lut[k];
+    plan.entries = 1u << (c.phi_width - 2 - c.z_shr);
+    plan.n_iter = c.n_iter;
+    plan.z_shl = c.z_shl;
+    plan.out_shr = c.out_shr;
+    plan.log2_entries = c.phi_width - 2 - c.z_shr;
+    plan.tab_split = c.tab_split;
+    plan.tab_dlog = c.tab_dlog;
+    plan.pad0 = 0;
+    plan.tab_coarse = c.tab_coarse;
+    plan.groups_per_wg = 64;
+    plan.pad = 0;
+    plan.x0 = c.x0;
+}
+
+int bhwk_coarse_build(const BhwLaunch &l, const BhwCordicCfg &c)
+{
+    if (!c.tab_dlog) return 0;
+    BHW_SET_DEVICE(l);
+    hipStream_t st = (hipStream_t)l.stream;
+    BhwBuildPlan plan;
+    fill_build_plan(c, plan);
+    const uint32_t cells = plan.entries >> c.tab_dlog;
+    const dim3 grid(grid_for(cells)), block(kBlock);
+    switch (c.n_iter) {
+#define BHW_CASE(N) case N: hipLaunchKernelGGL(k_coarse_build<N>, grid, block, 0, st, plan, (int4 *)const_cast<void *>(c.tab_coarse)); break;
+        BHW_CASE(7) BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14)
+        BHW_CASE(15) BHW_CASE(16) BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20) BHW_CASE(21) BHW_CASE(22)
+        BHW_CASE(23) BHW_CASE(24) BHW_CASE(25) BHW_CASE(26) BHW_CASE(27) BHW_CASE(28) BHW_CASE(29) BHW_CASE(30)
+        BHW_CASE(31) BHW_CASE(32)
+#undef BHW_CASE
+    default: return (int)hipErrorInvalidValue;
+    }
+    return finish(hipSuccess);
+}
+
 int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table)
 {
     BHW_SET_DEVICE(l);
@@ -906,13 +1026,16 @@ int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table
         plan.out_shr = c.out_shr;
         plan.log2_entries = c.phi_width - 2 - c.z_shr;
         plan.tab_split = c.tab_split;
+        plan.tab_dlog = c.tab_dlog;
+        plan.pad0 = 0;
+        plan.tab_coarse = c.tab_coarse;
         plan.x0 = c.x0;
         const unsigned groups = entries >> 6;
         plan.groups_per_wg = groups >= 64u * 1024u ? 64u : groups >= 16u * 1024u ? 16u : 4u;
         plan.pad = 0;
         const dim3 grid((groups + plan.groups_per_wg - 1) / plan.groups_per_wg), block(kBuildThreads);
         switch (c.n_iter) {
-#define BHW_CASE(N) case N: hipLaunchKernelGGL(k_table_build_shared<N>, grid, block, 0, st, plan, (int2 *)d_table); break;
+#define BHW_CASE(N) case N: hipLaunchKernelGGL(k_table_build_shared<N>, grid, block, 0, st, plan, (void *)d_table); break;
             BHW_CASE(7) BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14)
             BHW_CASE(15) BHW_CASE(16) BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20) BHW_CASE(21) BHW_CASE(22)
             BHW_CASE(23) BHW_CASE(24) BHW_CASE(25) BHW_CASE(26) BHW_CASE(27) BHW_CASE(28) BHW_CASE(29) BHW_CASE(30)
@@ -922,8 +1045,8 @@ int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table
         }
         return finish(hipSuccess);
     }
-    if (c.wide) hipLaunchKernelGGL(k_table_build<int64_t>, dim3(grid_for(entries)), dim3(kBlock), 0, st, c, entries, (int2 *)d_table);
-    else        hipLaunchKernelGGL(k_table_build<int32_t>, dim3(grid_for(entries)), dim3(kBlock), 0, st, c, entries, (int2 *)d_table);
+    if (c.wide) hipLaunchKernelGGL(k_table_build<int64_t>, dim3(grid_for(entries)), dim3(kBlock), 0, st, c, entries, (void *)d_table);
+    else        hipLaunchKernelGGL(k_table_build<int32_t>, dim3(grid_for(entries)), dim3(kBlock), 0, st, c, entries, (void *)d_table);
     return finish(hipSuccess);
 }
 
@@ -933,7 +1056,7 @@ int bhwk_table_combine(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCf
     if (!count) return 0;
     BHW_SET_DEVICE(l);
     hipStream_t st = (hipStream_t)l.stream;
-    hipLaunchKernelGGL(k_table_combine, dim3(grid_for(count)), dim3(kBlock), 0, st, c, w, (const int2 *)d_table, n0, count, d_out);
+    hipLaunchKernelGGL(k_table_combine, dim3(grid_for(count)), dim3(kBlock), 0, st, c, w, (const void *)d_table, n0, count, d_out);
     return finish(hipSuccess);
 }
 
@@ -942,7 +1065,7 @@ int bhwk_table_combine_fold(const BhwLaunch &l, const BhwCordicCfg &c, const Bhw
     BHW_SET_DEVICE(l);
     hipStream_t st = (hipStream_t)l.stream;
     const uint32_t quarter = 1u << (c.phi_width - 2);
-    hipLaunchKernelGGL(k_table_combine_fold, dim3(grid_for(quarter)), dim3(kBlock), 0, st, c, w, (const int2 *)d_table, d_out);
+    hipLaunchKernelGGL(k_table_combine_fold, dim3(grid_for(quarter)), dim3(kBlock), 0, st, c, w, (const void *)d_table, d_out);
     return finish(hipSuccess);
 }
 
@@ -998,15 +1121,15 @@ int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const Bhw
     const dim3 grid(tp.n_tiles), block(kTileThreads);
 #define BHW_LAUNCH_TILE(NB)                                                                                              \
     do {                                                                                                                 \
-        if (mode == 0)      hipLaunchKernelGGL((k_table_combine_tile<NB, 0>), grid, block, 0, st, c, w, tp, (const int2 *)d_table, d_out); \
-        else if (mode == 1) hipLaunchKernelGGL((k_table_combine_tile<NB, 1>), grid, block, 0, st, c, w, tp, (const int2 *)d_table, d_out); \
-        else                hipLaunchKernelGGL((k_table_combine_tile<NB, 2>), grid, block, 0, st, c, w, tp, (const int2 *)d_table, d_out); \
+        if (mode == 0)      hipLaunchKernelGGL((k_table_combine_tile<NB, 0>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
+        else if (mode == 1) hipLaunchKernelGGL((k_table_combine_tile<NB, 1>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
+        else                hipLaunchKernelGGL((k_table_combine_tile<NB, 2>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
     } while (0)
     if (nb == 15) {
         // 64-bit sums for 15 runs do not fit the register file: bhwk_tile_applicable() routes that case to the fold kernel
         if (mode == 2) return (int)hipErrorInvalidValue;
-        if (mode == 0) hipLaunchKernelGGL((k_table_combine_tile<15, 0>), grid, block, 0, st, c, w, tp, (const int2 *)d_table, d_out);
-        else           hipLaunchKernelGGL((k_table_combine_tile<15, 1>), grid, block, 0, st, c, w, tp, (const int2 *)d_table, d_out);
+        if (mode == 0) hipLaunchKernelGGL((k_table_combine_tile<15, 0>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out);
+        else           hipLaunchKernelGGL((k_table_combine_tile<15, 1>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out);
     }
     else if (nb == 3) BHW_LAUNCH_TILE(3);
     else BHW_LAUNCH_TILE(1);

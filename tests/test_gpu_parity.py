@@ -12,6 +12,7 @@ import oracle_lib as O
 from blackman_harris_win_amd import binding as B
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -361,6 +362,25 @@ def test_c3_full_64m(torch, golden):
     tail = bhw.generate(p, (1 << 26) - 1000, 2000, algo=B.ALGO_DIRECT)
     assert bool((tail[:1000] == full[-1000:]).all()) and bool((tail[1000:] == full[:1000]).all())
     del full
+
+
+def test_residual_compressed_table_is_exact(torch, golden):
+    """BHW_TABLE_COMPRESS=1 stores the shared table as 2-byte residuals against a linear predictor; results must not change."""
+    import subprocess, sys
+    code = (
+        "import hashlib, sys; sys.path.insert(0, %r)\n"
+        "import blackman_harris_win_amd as bhw\n"
+        "from blackman_harris_win_amd import binding as B\n"
+        "for win, pw, w, model in ((7, 26, 32, 0), (7, 24, 30, 1), (4, 22, 24, 2), (5, 21, 32, 0)):\n"
+        "    p = B.make_params(win, pw, w, model=model)\n"
+        "    a = bhw.generate(p, 12345, (1 << pw) + 99999, algo=B.ALGO_TABLE).cpu().numpy()\n"
+        "    print(hashlib.md5(a.tobytes()).hexdigest())\n" % ROOT)
+    outs = []
+    for flag in ("0", "1"):
+        env = dict(os.environ, BHW_TABLE_COMPRESS=flag)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, check=True)
+        outs.append(r.stdout.split())
+    assert outs[0] == outs[1] and len(outs[0]) == 4
 
 
 def test_c3_full_64m_model_cpp(torch, golden):
