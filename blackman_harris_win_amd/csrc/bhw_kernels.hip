@@ -562,8 +562,14 @@ __global__ __launch_bounds__(kTileThreads) void k_table_combine_tile(BhwCordicCf
     constexpr int NR = (NB + kParts - 1) / kParts;
     constexpr int kLanes = kTileThreads / kParts;
     const uint32_t part = threadIdx.x / kLanes;
-    const uint32_t rbase = blockIdx.x * kLanes + (threadIdx.x % kLanes);
     const uint32_t *offs = tp.offs + part * NR;        // padded with copies of the last run (idempotent stores)
+    // Lane -> r inside a run.  A run is kLanes consecutive r starting at (tile base + offs[b]), an arbitrary address, so a
+    // plain "lane i takes start + i" makes every wave's 256-byte output chunk straddle three cache lines (two partial).
+    // Rotating the lanes by the start's offset inside a 64-element block gives every wave an aligned block instead; only
+    // wave 0 is split (head of the first block + tail of the last).  Same set of r, same gathers, full-line stores:
+    // -1.25 % on the whole call (profiles/r01_ab_inproc.txt).
+    const uint32_t lane_in_part = threadIdx.x % kLanes;
+#define BHW_RUN_R(b) ((((blockIdx.x * kLanes + offs[b]) & hmask) + ((lane_in_part + kLanes - ((blockIdx.x * kLanes + offs[b]) & 63u)) % kLanes)) & hmask)
     acc_t acc[NR][2][4];
 #pragma unroll
     for (int b = 0; b < NR; ++b)
@@ -577,14 +583,14 @@ __global__ __launch_bounds__(kTileThreads) void k_table_combine_tile(BhwCordicCf
         constexpr int NG = (K & 1) ? 2 : 1;                                                              \
         int2 cs[NR][NG];                                                                                 \
         _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
-            const uint32_t r = (rbase + offs[b]) & hmask;                                             \
+            const uint32_t r = BHW_RUN_R(b);                                                             \
             _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                             \
                 const uint32_t theta = ((uint32_t)K * (r + (uint32_t)g * H)) & mask;                     \
                 cs[b][g] = tab_load(cfg, table, (theta & emask) >> cfg.z_shr, lq - cfg.z_shr);           \
             }                                                                                            \
         }                                                                                                \
         _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
-            const uint32_t r = (rbase + offs[b]) & hmask;                                             \
+            const uint32_t r = BHW_RUN_R(b);                                                             \
             _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                              \
                 const uint32_t theta = ((uint32_t)K * (r + (uint32_t)h * H)) & mask;                     \
                 tile_harmonic<K, MODE>(cfg, win.aa[K], W, win.combine, cs[b][NG == 2 ? h : 0], theta >> lq, acc[b][h]); \
@@ -601,7 +607,7 @@ __global__ __launch_bounds__(kTileThreads) void k_table_combine_tile(BhwCordicCf
 
 #pragma unroll
     for (int b = 0; b < NR; ++b) {
-        const uint32_t r = (rbase + offs[b]) & hmask;
+        const uint32_t r = BHW_RUN_R(b);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -612,6 +618,7 @@ __global__ __launch_bounds__(kTileThreads) void k_table_combine_tile(BhwCordicCf
                 emit(win, out, r + (uint32_t)h * H + (uint32_t)j * E, v);
             }
     }
+#undef BHW_RUN_R
 }
 
 // ---------------------------------------------------------------------------------------

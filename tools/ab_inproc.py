@@ -1,0 +1,78 @@
+"""In-process A/B of compile-time variants of libbhw.so (GPU box): every variant is built to its own .so, all are
+loaded side by side and timed interleaved on the same device and clocks, which removes the box-to-box and
+clock-ramp noise of separate bench runs.  usage: python tools/ab_inproc.py "<flags A>" "<flags B>" ...
+"""
+import ctypes
+import os
+import statistics
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from blackman_harris_win_amd import _build, binding  # noqa: E402
+
+
+def build_variant(idx, flags):
+    out = os.path.join(ROOT, "gpurun_out", f"libbhw_ab{idx}.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    csrc = _build.CSRC
+    rom_o = os.path.join(csrc, "bhw_rom.o")
+    if not os.path.exists(rom_o):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-c", os.path.join(csrc, "bhw_rom.c"), "-o", rom_o])
+    quad = subprocess.run(["gcc", "-print-file-name=libquadmath.so"], stdout=subprocess.PIPE, text=True).stdout.strip()
+    cmd = [_build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function"] + \
+        flags.split() + ["-x", "hip", os.path.join(csrc, "bhw_api.cpp"), os.path.join(csrc, "bhw_kernels.hip"),
+                         "-x", "none", rom_o, quad, "-Wl,-rpath," + os.path.dirname(os.path.realpath(quad)), "-o", out]
+    subprocess.check_call(cmd)
+    return out
+
+
+def main():
+    variants = sys.argv[1:]
+    pw = int(os.environ.get("AB_PW", "26"))
+    win = int(os.environ.get("AB_WIN", "7"))
+    width = int(os.environ.get("AB_W", "32"))
+    rounds = int(os.environ.get("AB_ROUNDS", "8"))
+    inner = int(os.environ.get("AB_INNER", "100"))
+    torch.zeros(1, device="cuda")
+    libs = []
+    for i, f in enumerate(variants):
+        L = ctypes.CDLL(build_variant(i, f))
+        L.bhw_generate_device.argtypes = [ctypes.POINTER(binding.BhwParams), ctypes.c_int, ctypes.c_void_p,
+                                          ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+        L.bhw_params_init.argtypes = [ctypes.POINTER(binding.BhwParams), ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+        libs.append(L)
+    n = 1 << pw
+    out = torch.empty(n, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    p = binding.BhwParams()
+    libs[0].bhw_params_init(ctypes.byref(p), win, pw, width)
+    ref = None
+    for L in libs:
+        rc = L.bhw_generate_device(ctypes.byref(p), 0, ctypes.c_void_p(st), 0, n, ctypes.c_void_p(out.data_ptr()))
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = out.clone()
+        else:
+            assert torch.equal(ref, out), "variants disagree"
+    times = [[] for _ in libs]
+    for r in range(rounds + 1):
+        for i, L in enumerate(libs):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(inner):
+                L.bhw_generate_device(ctypes.byref(p), 0, ctypes.c_void_p(st), 0, n, ctypes.c_void_p(out.data_ptr()))
+            e1.record()
+            torch.cuda.synchronize()
+            if r:   # round 0 = clock ramp
+                times[i].append(e0.elapsed_time(e1) / inner)
+    for f, t in zip(variants, times):
+        print("%-44s median %.4f ms  min %.4f  max %.4f" % ("[" + f + "]", statistics.median(t), min(t), max(t)))
+
+
+if __name__ == "__main__":
+    main()
