@@ -70,11 +70,18 @@ __device__ __forceinline__ int64_t wrap_bits(int64_t v, uint32_t bits)
 // Table layouts.  Natural: entry u at index u.  Split: the table is stored as three runs
 //   [ u % 4 == 0 | u % 4 == 2 | u odd ]  so that the even harmonics (t = 2r, 4r, 6r only ever touch even /
 // multiple-of-4 entries) read dense runs instead of every 2nd / 4th entry of a line.
+// KCLASS states what the caller knows about u at compile time (from the harmonic number): 0 nothing, 2 u is even,
+// 4 u is a multiple of 4.  Branch-free on purpose: as a ?: chain the compiler emits exec-mask branches per gather.
+template <int KCLASS = 0>
 __device__ __forceinline__ uint32_t tab_index(uint32_t u, uint32_t log2_entries, uint32_t split)
 {
     if (!split) return u;
     const uint32_t e = 1u << log2_entries;
-    return (u & 1u) ? (e >> 1) + (u >> 1) : (u & 2u) ? (e >> 2) + (u >> 2) : (u >> 2);
+    if constexpr (KCLASS == 4) return u >> 2;
+    const uint32_t mid = (e >> 2) & (0u - ((u >> 1) & 1u));            // u % 4 == 2 -> second run
+    if constexpr (KCLASS == 2) return (u >> 2) + mid;
+    const uint32_t odd = u & 1u;
+    return (u >> (2u - odd)) + (odd ? (e >> 1) : mid);
 }
 
 // Residual-compressed table (cfg.tab_dlog = d > 0, z_shr == 0 only).  (c, s)(t) is smooth in t: between two exact
@@ -89,10 +96,11 @@ __device__ __forceinline__ int2 tab_predict(const int4 rec, uint32_t f, uint32_t
     return make_int2(rec.x + ((rec.z * (int32_t)f) >> d), rec.y + ((rec.w * (int32_t)f) >> d));
 }
 
+template <int KCLASS = 0, bool COMP = true>
 __device__ __forceinline__ int2 tab_load(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t log2_entries)
 {
-    const uint32_t idx = tab_index(u, log2_entries, cfg.tab_split);
-    const uint32_t d = cfg.tab_dlog;
+    const uint32_t idx = tab_index<KCLASS>(u, log2_entries, cfg.tab_split);
+    const uint32_t d = COMP ? cfg.tab_dlog : 0u;
     if (d == 0) return reinterpret_cast<const int2 *>(table)[idx];
     const uint32_t r = reinterpret_cast<const uint16_t *>(table)[idx];
     const int4 rec = reinterpret_cast<const int4 *>(cfg.tab_coarse)[u >> d];
@@ -548,7 +556,7 @@ __device__ __forceinline__ void tile_harmonic(const BhwCordicCfg &cfg, const int
 // Lane r in [0, E/2) owns the eight coefficients n = r + h*E/2 + j*E (h = 0,1; j = 0..3).  For even k the
 // two h-images share one gather (k*E/2 is a whole number of quadrants); for odd k the second image reads
 // entry t + E/2, another dense span of the same tile.
-template <int NB, int MODE>
+template <int NB, int MODE, bool COMP>
 __global__ __launch_bounds__(kTileThreads) void k_table_combine_tile(BhwCordicCfg cfg, BhwWinCfg win, BhwTilePlan tp,
                                                                       const void *__restrict__ table, int32_t *__restrict__ out)
 {
@@ -581,12 +589,13 @@ __global__ __launch_bounds__(kTileThreads) void k_table_combine_tile(BhwCordicCf
 #define BHW_TILE_HARMONIC(K)                                                                             \
     if (win.n_terms > K) {                                                                               \
         constexpr int NG = (K & 1) ? 2 : 1;                                                              \
+        constexpr int KC = (K % 4 == 0) ? 4 : (K % 2 == 0) ? 2 : 0;   /* split layout only exists at z_shr == 0 */ \
         int2 cs[NR][NG];                                                                                 \
         _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
             const uint32_t r = BHW_RUN_R(b);                                                             \
             _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                             \
                 const uint32_t theta = ((uint32_t)K * (r + (uint32_t)g * H)) & mask;                     \
-                cs[b][g] = tab_load(cfg, table, (theta & emask) >> cfg.z_shr, lq - cfg.z_shr);           \
+                cs[b][g] = tab_load<KC, COMP>(cfg, table, (theta & emask) >> cfg.z_shr, lq - cfg.z_shr); \
             }                                                                                            \
         }                                                                                                \
         _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
@@ -1126,20 +1135,26 @@ int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const Bhw
     tp.n_tiles = (uint32_t)((maxgap + lanes - 1) / lanes);
     const int mode = (w.combine != BHW_COMBINE_HLS) ? 2 : (c.ones_neg ? 1 : 0);
     const dim3 grid(tp.n_tiles), block(kTileThreads);
+#define BHW_LAUNCH_TILE_M(NB, M)                                                                                         \
+    do {                                                                                                                 \
+        if (c.tab_dlog) hipLaunchKernelGGL((k_table_combine_tile<NB, M, true>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
+        else            hipLaunchKernelGGL((k_table_combine_tile<NB, M, false>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
+    } while (0)
 #define BHW_LAUNCH_TILE(NB)                                                                                              \
     do {                                                                                                                 \
-        if (mode == 0)      hipLaunchKernelGGL((k_table_combine_tile<NB, 0>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
-        else if (mode == 1) hipLaunchKernelGGL((k_table_combine_tile<NB, 1>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
-        else                hipLaunchKernelGGL((k_table_combine_tile<NB, 2>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
+        if (mode == 0)      BHW_LAUNCH_TILE_M(NB, 0);                                                                    \
+        else if (mode == 1) BHW_LAUNCH_TILE_M(NB, 1);                                                                    \
+        else                BHW_LAUNCH_TILE_M(NB, 2);                                                                    \
     } while (0)
     if (nb == 15) {
         // 64-bit sums for 15 runs do not fit the register file: bhwk_tile_applicable() routes that case to the fold kernel
         if (mode == 2) return (int)hipErrorInvalidValue;
-        if (mode == 0) hipLaunchKernelGGL((k_table_combine_tile<15, 0>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out);
-        else           hipLaunchKernelGGL((k_table_combine_tile<15, 1>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out);
+        if (mode == 0) BHW_LAUNCH_TILE_M(15, 0);
+        else           BHW_LAUNCH_TILE_M(15, 1);
     }
     else if (nb == 3) BHW_LAUNCH_TILE(3);
     else BHW_LAUNCH_TILE(1);
+#undef BHW_LAUNCH_TILE_M
 #undef BHW_LAUNCH_TILE
     return finish(hipSuccess);
 }
