@@ -69,15 +69,17 @@ __device__ __forceinline__ int64_t wrap_bits(int64_t v, uint32_t bits)
 
 // Table layouts.  Natural: entry u at index u.  Split: the table is stored as three runs
 //   [ u % 4 == 0 | u % 4 == 2 | u odd ]  so that the even harmonics (t = 2r, 4r, 6r only ever touch even /
-// multiple-of-4 entries) read dense runs instead of every 2nd / 4th entry of a line.
+// multiple-of-4 entries) read dense runs instead of every 2nd / 4th entry of a line.  (Four runs by u % 4 -- a plain
+// rotate of the index -- cost 5 % more: a wave of consecutive odd-harmonic lanes then reads four 128-byte pieces
+// instead of one 256-byte piece and two of 128, profiles/r01_ab_inproc.txt.)
 // KCLASS states what the caller knows about u at compile time (from the harmonic number): 0 nothing, 2 u is even,
 // 4 u is a multiple of 4.  Branch-free on purpose: as a ?: chain the compiler emits exec-mask branches per gather.
 template <int KCLASS = 0>
 __device__ __forceinline__ uint32_t tab_index(uint32_t u, uint32_t log2_entries, uint32_t split)
 {
     if (!split) return u;
-    const uint32_t e = 1u << log2_entries;
     if constexpr (KCLASS == 4) return u >> 2;
+    const uint32_t e = 1u << log2_entries;
     const uint32_t mid = (e >> 2) & (0u - ((u >> 1) & 1u));            // u % 4 == 2 -> second run
     if constexpr (KCLASS == 2) return (u >> 2) + mid;
     const uint32_t odd = u & 1u;
@@ -505,6 +507,10 @@ __global__ __launch_bounds__(kBlock) void k_table_combine_fold(BhwCordicCfg cfg,
 #ifndef BHW_TILE_LANES
 #define BHW_TILE_LANES 256
 #endif
+#ifndef BHW_TILE_WAVES
+#define BHW_TILE_WAVES 5      // waves per SIMD the tile kernel is register-allocated for: one 768-thread workgroup per CU with
+                              // ~83 VGPRs beats two with 80 and spills (0.2244 vs 0.2323 ms, profiles/r01_ab_inproc.txt)
+#endif
 constexpr int kTileThreads = BHW_TILE_THREADS;
 constexpr int kTileLanes = BHW_TILE_LANES;     // tile width in lanes; the tile's 15 runs are split over kTileThreads / kTileLanes thread groups
 
@@ -532,15 +538,27 @@ __device__ __forceinline__ void tile_harmonic(const BhwCordicCfg &cfg, const int
         combine_term(p2, a, nc, K, W, combine);
         combine_term(p3, a, cs.y, K, W, combine);
     } else {
-        const int32_t nc = MODE == 1 ? ~cs.x : -cs.x;
-        const int32_t ns = MODE == 1 ? ~cs.y : -cs.y;
         const uint32_t sh = W - 2;                         // mlt_k = (a_k * c_k) >> (NWIDTH-2), win_function.cpp:368-373
-        const int32_t m0 = (int32_t)(((int64_t)a * cs.x) >> sh), m1 = (int32_t)(((int64_t)a * ns) >> sh);
-        const int32_t m2 = (int32_t)(((int64_t)a * nc) >> sh), m3 = (int32_t)(((int64_t)a * cs.y) >> sh);
-        p0 = (K & 1) ? -m0 : m0;                           // a0 - m1 + m2 - m3 + ...
-        p1 = (K & 1) ? -m1 : m1;
-        p2 = (K & 1) ? -m2 : m2;
-        p3 = (K & 1) ? -m3 : m3;
+        if constexpr (MODE == 1) {
+            const int32_t nc = ~cs.x, ns = ~cs.y;
+            const int32_t m0 = (int32_t)(((int64_t)a * cs.x) >> sh), m1 = (int32_t)(((int64_t)a * ns) >> sh);
+            const int32_t m2 = (int32_t)(((int64_t)a * nc) >> sh), m3 = (int32_t)(((int64_t)a * cs.y) >> sh);
+            p0 = (K & 1) ? -m0 : m0;                       // a0 - m1 + m2 - m3 + ...
+            p1 = (K & 1) ? -m1 : m1;
+            p2 = (K & 1) ? -m2 : m2;
+            p3 = (K & 1) ? -m3 : m3;
+        } else {
+            // two's-complement map: the products with -c and -s come from the same 64-bit product,
+            //   floor(-P / 2^sh) = -(floor(P / 2^sh) + (P mod 2^sh != 0)),  all modulo 2^32 (sh <= 30)
+            const int64_t Pc = (int64_t)a * cs.x, Ps = (int64_t)a * cs.y;
+            const uint32_t low = (1u << sh) - 1u;
+            const int32_t mc = (int32_t)(Pc >> sh), ms = (int32_t)(Ps >> sh);
+            const int32_t uc = mc + ((((uint32_t)Pc) & low) != 0u), us = ms + ((((uint32_t)Ps) & low) != 0u);   // = -m(-c), -m(-s)
+            p0 = (K & 1) ? -mc : mc;
+            p1 = (K & 1) ? us : -us;
+            p2 = (K & 1) ? uc : -uc;
+            p3 = (K & 1) ? -ms : ms;
+        }
     }
     // rotate the four candidates by q so that image j (quadrant q + j*K) reads a fixed slot
     const bool b0 = q & 1u, b1 = q & 2u;
@@ -557,27 +575,30 @@ __device__ __forceinline__ void tile_harmonic(const BhwCordicCfg &cfg, const int
 // two h-images share one gather (k*E/2 is a whole number of quadrants); for odd k the second image reads
 // entry t + E/2, another dense span of the same tile.
 template <int NB, int MODE, bool COMP>
-__global__ __launch_bounds__(kTileThreads) void k_table_combine_tile(BhwCordicCfg cfg, BhwWinCfg win, BhwTilePlan tp,
+__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(BHW_TILE_WAVES))) void k_table_combine_tile(BhwCordicCfg cfg, BhwWinCfg win, BhwTilePlan tp,
                                                                       const void *__restrict__ table, int32_t *__restrict__ out)
 {
     using acc_t = typename std::conditional<MODE == 2, int64_t, int32_t>::type;
     const uint32_t lq = cfg.phi_width - 2;
     const uint32_t E = 1u << lq, emask = E - 1u, H = E >> 1, hmask = H - 1u;
-    const uint32_t mask = (cfg.phi_width >= 32) ? 0xFFFFFFFFu : ((1u << cfg.phi_width) - 1u);
     const uint32_t W = cfg.dat_width;
     // thread group `part` of the workgroup takes runs [part*NR, part*NR + NR) of the tile (registers: NR*8 sums)
     constexpr int kParts = (NB >= 15) ? kTileThreads / kTileLanes : 1;
     constexpr int NR = (NB + kParts - 1) / kParts;
     constexpr int kLanes = kTileThreads / kParts;
-    const uint32_t part = threadIdx.x / kLanes;
-    const uint32_t *offs = tp.offs + part * NR;        // padded with copies of the last run (idempotent stores)
     // Lane -> r inside a run.  A run is kLanes consecutive r starting at (tile base + offs[b]), an arbitrary address, so a
     // plain "lane i takes start + i" makes every wave's 256-byte output chunk straddle three cache lines (two partial).
     // Rotating the lanes by the start's offset inside a 64-element block gives every wave an aligned block instead; only
     // wave 0 is split (head of the first block + tail of the last).  Same set of r, same gathers, full-line stores:
     // -1.25 % on the whole call (profiles/r01_ab_inproc.txt).
+    const uint32_t part = __builtin_amdgcn_readfirstlane(threadIdx.x / kLanes);   // wave-uniform: kLanes is a multiple of 64
     const uint32_t lane_in_part = threadIdx.x % kLanes;
-#define BHW_RUN_R(b) ((((blockIdx.x * kLanes + offs[b]) & hmask) + ((lane_in_part + kLanes - ((blockIdx.x * kLanes + offs[b]) & 63u)) % kLanes)) & hmask)
+    uint32_t rr[NR];
+#pragma unroll
+    for (int b = 0; b < NR; ++b) {
+        const uint32_t start = (blockIdx.x * kLanes + tp.offs[part * NR + b]) & hmask;   // scalar; offs padded with copies of the last run
+        rr[b] = (start + (lane_in_part + kLanes - (start & 63u)) % kLanes) & hmask;
+    }
     acc_t acc[NR][2][4];
 #pragma unroll
     for (int b = 0; b < NR; ++b)
@@ -592,16 +613,14 @@ __global__ __launch_bounds__(kTileThreads) void k_table_combine_tile(BhwCordicCf
         constexpr int KC = (K % 4 == 0) ? 4 : (K % 2 == 0) ? 2 : 0;   /* split layout only exists at z_shr == 0 */ \
         int2 cs[NR][NG];                                                                                 \
         _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
-            const uint32_t r = BHW_RUN_R(b);                                                             \
             _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                             \
-                const uint32_t theta = ((uint32_t)K * (r + (uint32_t)g * H)) & mask;                     \
+                const uint32_t theta = (uint32_t)K * (rr[b] + (uint32_t)g * H);                          \
                 cs[b][g] = tab_load<KC, COMP>(cfg, table, (theta & emask) >> cfg.z_shr, lq - cfg.z_shr); \
             }                                                                                            \
         }                                                                                                \
         _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
-            const uint32_t r = BHW_RUN_R(b);                                                             \
             _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                              \
-                const uint32_t theta = ((uint32_t)K * (r + (uint32_t)h * H)) & mask;                     \
+                const uint32_t theta = (uint32_t)K * (rr[b] + (uint32_t)h * H);   /* only quadrant bits 0,1 are used */ \
                 tile_harmonic<K, MODE>(cfg, win.aa[K], W, win.combine, cs[b][NG == 2 ? h : 0], theta >> lq, acc[b][h]); \
             }                                                                                            \
         }                                                                                                \
@@ -616,7 +635,7 @@ __global__ __launch_bounds__(kTileThreads) void k_table_combine_tile(BhwCordicCf
 
 #pragma unroll
     for (int b = 0; b < NR; ++b) {
-        const uint32_t r = BHW_RUN_R(b);
+        const uint32_t r = rr[b];
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -627,7 +646,6 @@ __global__ __launch_bounds__(kTileThreads) void k_table_combine_tile(BhwCordicCf
                 emit(win, out, r + (uint32_t)h * H + (uint32_t)j * E, v);
             }
     }
-#undef BHW_RUN_R
 }
 
 // ---------------------------------------------------------------------------------------
