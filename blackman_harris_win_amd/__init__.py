@@ -17,7 +17,7 @@ from .binding import (  # noqa: F401
     ALGO_AUTO, ALGO_DIRECT, ALGO_TABLE,
     COMBINE_HLS, COMBINE_VHDL,
     MODEL_CPP, MODEL_HLS, MODEL_VHDL,
-    SIN_CORDIC, SIN_TAYLOR,
+    SIN_CORDIC, SIN_TAYLOR, SIN_TAYLOR_ALL,
     WIN_BH3, WIN_BH4, WIN_BH5, WIN_BH7, WIN_HAMMING, WIN_HANN,
     BhwError, BhwParams, coeffs_from_float, constant_tables, lib, lib_path, make_params,
 )

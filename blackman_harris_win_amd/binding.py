@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 MODEL_HLS, MODEL_CPP, MODEL_VHDL = 0, 1, 2
 COMBINE_HLS, COMBINE_VHDL = 0, 1
-SIN_CORDIC, SIN_TAYLOR = 0, 1
+SIN_CORDIC, SIN_TAYLOR, SIN_TAYLOR_ALL = 0, 1, 2
 WIN_HAMMING, WIN_HANN, WIN_BH3, WIN_BH4, WIN_BH5, WIN_BH7 = 1, 2, 3, 4, 5, 7
 ALGO_AUTO, ALGO_DIRECT, ALGO_TABLE = 0, 1, 2
 

@@ -73,18 +73,22 @@ int validate(const bhw_params *p)
         return fail(BHW_ERR_BADARG, "struct_size %u != %zu", p->struct_size, sizeof(bhw_params));
     if (p->model > BHW_MODEL_VHDL) return fail(BHW_ERR_BADARG, "model %u", p->model);
     if (p->combine > BHW_COMBINE_VHDL) return fail(BHW_ERR_BADARG, "combine %u", p->combine);
-    if (p->sin_type > BHW_SIN_TAYLOR) return fail(BHW_ERR_BADARG, "sin_type %u", p->sin_type);
+    if (p->sin_type > BHW_SIN_TAYLOR_ALL) return fail(BHW_ERR_BADARG, "sin_type %u", p->sin_type);
     const uint32_t K = p->n_terms;
     if (!(K == 2 || K == 3 || K == 4 || K == 5 || K == 7)) return fail(BHW_ERR_BADARG, "n_terms %u (2,3,4,5,7)", K);
     const uint32_t PW = p->phi_width, W = p->dat_width;
     if (PW < 4 || PW > 30) return fail(BHW_ERR_BADARG, "phi_width %u outside 4..30", PW);
     if (W < 8 || W > 32) return fail(BHW_ERR_BADARG, "dat_width %u outside 8..32", W);
-    if (p->sin_type == BHW_SIN_TAYLOR) {
+    if (p->sin_type != BHW_SIN_CORDIC) {
         // win_selector wires the Taylor source only to HAMMING and BH3TERM: src/win_selector.vhd:93-135
-        if (K > 3) return fail(BHW_ERR_UNSUPPORTED, "Taylor source exists only for 2- and 3-term windows");
+        if (K > 3 && p->sin_type == BHW_SIN_TAYLOR)
+            return fail(BHW_ERR_UNSUPPORTED, "Taylor source exists only for 2- and 3-term windows (BHW_SIN_TAYLOR_ALL is the extension)");
         const uint32_t L = p->lut_size;
         if (L < 1 || L > 16) return fail(BHW_ERR_BADARG, "lut_size %u outside 1..16", L);
-        const uint32_t pw_min = (K == 3) ? PW - 1 : PW;  // bh_win_3term.vhd:221-226
+        // generators in use: PHASE_WIDTH - v, v = 0 .. vmax  (bh_win_3term.vhd:221-226; k = 4 needs v = 2)
+        const uint32_t vmax = K > 4 ? 2u : K > 2 ? 1u : 0u;
+        if (PW < 3 + vmax) return fail(BHW_ERR_UNSUPPORTED, "phi_width %u too short for the PHASE_WIDTH-%u generator", PW, vmax);
+        const uint32_t pw_min = PW - vmax;
         for (uint32_t pw = pw_min; pw <= PW; ++pw) {
             const int d = (int)pw - (int)L;
             if (d > 2) {
@@ -216,7 +220,8 @@ int resolve_taylor(const bhw_params *p, int device, void *stream, BhwTaylorCfg &
     t.mode = d < 2 ? 0u : d == 2 ? 1u : 2u;
     t.xshift = 19 + p->lut_size;
     t.pi_word = d > 2 ? bhw_taylor_pi_word(17 - (d - 3)) : 0;          // tay1_order.vhd:133, STAGE = PW-L-3
-    t.pad[0] = (d - 1) > 2 ? bhw_taylor_pi_word(17 - (d - 4)) : 0;      // 2nd generator at PHASE_WIDTH-1
+    t.pad[0] = (d - 1) > 2 ? bhw_taylor_pi_word(17 - (d - 4)) : 0;      // generator at PHASE_WIDTH-1 (harmonics 2, 6)
+    t.pad[1] = (d - 2) > 2 ? bhw_taylor_pi_word(17 - (d - 5)) : 0;      // generator at PHASE_WIDTH-2 (harmonic 4)
     return get_taylor_rom(device, stream, p->dat_width, p->lut_size, &t.rom);
 }
 
@@ -232,7 +237,7 @@ uint64_t table_entries(const BhwCordicCfg &c) { return 1ull << (c.phi_width - 2 
 // AUTO: build the shared table when it replaces clearly more CORDIC chains than it costs.
 uint32_t pick_algo(const bhw_params *p, const BhwCordicCfg &c, uint64_t count, uint32_t requested)
 {
-    if (p->sin_type == BHW_SIN_TAYLOR) return BHW_ALGO_DIRECT;
+    if (p->sin_type != BHW_SIN_CORDIC) return BHW_ALGO_DIRECT;
     if (requested == BHW_ALGO_DIRECT || requested == BHW_ALGO_TABLE) return requested;
     const uint64_t chains_direct = count * (p->n_terms - 1);
     return chains_direct >= 2 * table_entries(c) ? BHW_ALGO_TABLE : BHW_ALGO_DIRECT;
@@ -282,7 +287,7 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
     resolve_window(p, w);
     w.apply_x = apply_x;
     w.apply_shift = apply_shift;
-    if (p->sin_type == BHW_SIN_TAYLOR) {
+    if (p->sin_type != BHW_SIN_CORDIC) {
         BhwTaylorCfg t;
         rc = resolve_taylor(p, device, stream, t);
         if (rc) return rc;
@@ -452,7 +457,7 @@ uint64_t bhw_workspace_bytes(const bhw_params *p, uint64_t n0, uint64_t count, u
 {
     (void)n0;
     if (validate(p)) return 0;
-    if (p->sin_type == BHW_SIN_TAYLOR) return 0;
+    if (p->sin_type != BHW_SIN_CORDIC) return 0;
     BhwCordicCfg c;
     resolve_cordic(p, c);
     return pick_algo(p, c, count, algo) == BHW_ALGO_TABLE ? table_entries(c) * 8ull : 0;
@@ -482,7 +487,7 @@ int bhw_sincos_device(const bhw_params *p, int device, void *hip_stream, uint64_
     if (!d_sin && !d_cos) return fail(BHW_ERR_BADARG, "both outputs NULL");
     if (!device_ok(device)) return fail(BHW_ERR_HIP, "no usable HIP device %d (this library has no CPU path)", device);
     BhwLaunch l{device, hip_stream};
-    if (p->sin_type == BHW_SIN_TAYLOR) {
+    if (p->sin_type != BHW_SIN_CORDIC) {
         BhwTaylorCfg t;
         rc = resolve_taylor(p, device, hip_stream, t);
         if (rc) return rc;

@@ -718,6 +718,18 @@ __device__ __forceinline__ void taylor_full(const BhwTaylorCfg &t, uint32_t cnt,
     os = (int32_t)((q == 0) ? s : (q == 1) ? c : (q == 2) ? ns : nc);
 }
 
+// Generator of harmonic k = m * 2^v: taylor_sincos at PHASE_WIDTH - v (bh_win_3term.vhd:221-226 for k = 2; continued to
+// k = 3..6 by BHW_SIN_TAYLOR_ALL, include/bhw.h).  pad[v-1] holds that generator's pi word.
+__device__ __forceinline__ BhwTaylorCfg taylor_gen(const BhwTaylorCfg &t, uint32_t v)
+{
+    BhwTaylorCfg g = t;
+    g.phi_width = t.phi_width - v;
+    const int d = (int)g.phi_width - (int)g.lut_size;
+    g.mode = d < 2 ? 0u : d == 2 ? 1u : 2u;
+    g.pi_word = v == 0 ? t.pi_word : t.pad[v - 1];
+    return g;
+}
+
 // ---- 32-bit forms for dat_width <= 16 (every product a*v and every sum fits int32; same results) ----
 __device__ __forceinline__ int32_t wrap32(int32_t v, uint32_t bits)
 {
@@ -817,14 +829,46 @@ __global__ __launch_bounds__(kBlock) void k_taylor_window_fold(BhwTaylorCfg t, B
         if constexpr (NARROW) return wrap32(-(int32_t)v, W);
         else return (int32_t)wrap_bits(-(int64_t)v, W);
     };
-    BhwTaylorCfg t2 = t;                                         // second generator of the 3-term window
-    t2.phi_width = t.phi_width - 1;
-    {
-        const int d = (int)t2.phi_width - (int)t2.lut_size;
-        t2.mode = FAST ? 2u : (d < 2 ? 0u : d == 2 ? 1u : 2u);
-        t2.pi_word = t.pad[0];
-    }
-    const uint32_t half = E >> 1;                                // quarter period of the second generator
+    // generators by valuation v = 0, 1, 2 of the harmonic number (k = 1,3,5 | 2,6 | 4)
+    BhwTaylorCfg tg[3] = {taylor_gen(t, 0), taylor_gen(t, NTERMS > 2 ? 1 : 0), taylor_gen(t, NTERMS > 4 ? 2 : 0)};
+    if constexpr (FAST) { tg[0].mode = tg[1].mode = tg[2].mode = 2u; }
+    // harmonic K of lane r: phase (m*r) mod 2^(PW-v) in generator v; image j sits K*j quadrants further on
+    auto harmonic = [&](auto kc, uint32_t r, val_t (&acc)[4]) {
+        constexpr uint32_t K = decltype(kc)::value;
+        constexpr uint32_t V = (K & 1u) ? 0u : (K & 2u) ? 1u : 2u, M = K >> V;
+        const BhwTaylorCfg &g = tg[V];
+        const uint32_t cnt = (M * r) & ((4u * E >> V) - 1u);
+        const uint32_t q0 = (K == 1u) ? 0u : cnt >> (g.phi_width - 2u);
+        val_t s, c;
+        if constexpr (NARROW) { if (in_lds) taylor_q1_narrow(g, rom_s, cnt, s, c); else taylor_q1_narrow(g, rom_g, cnt, s, c); }
+        else                  { if (in_lds) taylor_q1(g, rom_s, cnt, s, c);        else taylor_q1(g, rom_g, cnt, s, c); }
+        const int32_t p0 = (int32_t)c, p1 = neg(s), p2 = neg(c), p3 = (int32_t)s;   // quadrant 0..3: taylor_sincos.vhd:240-253
+        if constexpr (K == 1u) {
+            add_term(acc[0], win.aa[1], p0, 1);
+            add_term(acc[1], win.aa[1], p1, 1);
+            add_term(acc[2], win.aa[1], p2, 1);
+            add_term(acc[3], win.aa[1], p3, 1);
+        } else {
+            const bool b0 = q0 & 1u, b1 = q0 & 2u;
+            const int32_t r0 = b0 ? p1 : p0, r1 = b0 ? p2 : p1, r2 = b0 ? p3 : p2, r3 = b0 ? p0 : p3;
+            const int32_t sv[4] = {b1 ? r2 : r0, b1 ? r3 : r1, b1 ? r0 : r2, b1 ? r1 : r3};
+            if constexpr ((K & 3u) == 0u) {                      // all four images in one quadrant
+                val_t one = 0;
+                add_term(one, win.aa[K], sv[0], K);
+                acc[0] += one; acc[1] += one; acc[2] += one; acc[3] += one;
+            } else if constexpr ((K & 1u) == 0u) {               // images alternate between two quadrants
+                val_t even = 0, odd = 0;
+                add_term(even, win.aa[K], sv[0], K);
+                add_term(odd, win.aa[K], sv[2], K);
+                acc[0] += even; acc[1] += odd; acc[2] += even; acc[3] += odd;
+            } else {
+                add_term(acc[0], win.aa[K], sv[0], K);
+                add_term(acc[1], win.aa[K], sv[K & 3u], K);
+                add_term(acc[2], win.aa[K], sv[(2u * K) & 3u], K);
+                add_term(acc[3], win.aa[K], sv[(3u * K) & 3u], K);
+            }
+        }
+    };
     // grid-stride over 1024-coefficient-wide chunks of r: the ROM staging above is paid once per workgroup
     for (uint32_t r0 = (blockIdx.x * kBlock + threadIdx.x) * 4u; r0 < E; r0 += gridDim.x * kBlock * 4u) {
     int32_t res[4][4];                                           // [image j][i]
@@ -832,25 +876,13 @@ __global__ __launch_bounds__(kBlock) void k_taylor_window_fold(BhwTaylorCfg t, B
     for (int i = 0; i < 4; ++i) {
         const uint32_t r = r0 + (uint32_t)i;
         val_t acc[4] = {(val_t)win.aa[0], (val_t)win.aa[0], (val_t)win.aa[0], (val_t)win.aa[0]};
-        {
-            val_t s, c;
-            if constexpr (NARROW) { if (in_lds) taylor_q1_narrow(t, rom_s, r, s, c); else taylor_q1_narrow(t, rom_g, r, s, c); }
-            else                  { if (in_lds) taylor_q1(t, rom_s, r, s, c);        else taylor_q1(t, rom_g, r, s, c); }
-            const int32_t v[4] = {(int32_t)c, neg(s), neg(c), (int32_t)s};       // quadrant j: taylor_sincos.vhd:240-253
-#pragma unroll
-            for (int j = 0; j < 4; ++j) add_term(acc[j], win.aa[1], v[j], 1);
-        }
-        if constexpr (NTERMS > 2) {
-            val_t s, c;
-            if constexpr (NARROW) { if (in_lds) taylor_q1_narrow(t2, rom_s, r & (half - 1u), s, c); else taylor_q1_narrow(t2, rom_g, r & (half - 1u), s, c); }
-            else                  { if (in_lds) taylor_q1(t2, rom_s, r & (half - 1u), s, c);        else taylor_q1(t2, rom_g, r & (half - 1u), s, c); }
-            const bool hi = r >= half;                           // quadrant 0 or 1 at j even, 2 or 3 at j odd
-            const int32_t even = hi ? neg(s) : (int32_t)c;       // quadrant 0: c, 1: -s
-            const int32_t odd = hi ? (int32_t)s : neg(c);        // quadrant 2: -c, 3: s
-            add_term(acc[0], win.aa[2], even, 2);
-            add_term(acc[1], win.aa[2], odd, 2);
-            add_term(acc[2], win.aa[2], even, 2);
-            add_term(acc[3], win.aa[2], odd, 2);
+        harmonic(std::integral_constant<uint32_t, 1>{}, r, acc);
+        if constexpr (NTERMS > 2) harmonic(std::integral_constant<uint32_t, 2>{}, r, acc);
+        if constexpr (NTERMS > 3) harmonic(std::integral_constant<uint32_t, 3>{}, r, acc);
+        if constexpr (NTERMS > 4) harmonic(std::integral_constant<uint32_t, 4>{}, r, acc);
+        if constexpr (NTERMS > 5) {
+            harmonic(std::integral_constant<uint32_t, 5>{}, r, acc);
+            harmonic(std::integral_constant<uint32_t, 6>{}, r, acc);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -881,17 +913,9 @@ __global__ __launch_bounds__(kBlock) void k_taylor_window(BhwTaylorCfg t, BhwWin
     int64_t acc = win.aa[0];
     for (uint32_t k = 1; k < win.n_terms; ++k) {
         int32_t c, s;
-        if (k == 1) {
-            taylor_full(t, n, c, s);
-        } else {
-            // 2nd harmonic = a second generator with PHASE_WIDTH-1 on its own +1 counter: bh_win_3term.vhd:221-226
-            BhwTaylorCfg t2 = t;
-            t2.phi_width = t.phi_width - 1;
-            const int d = (int)t2.phi_width - (int)t2.lut_size;
-            t2.mode = d < 2 ? 0u : d == 2 ? 1u : 2u;
-            t2.pi_word = t.pad[0];
-            taylor_full(t2, n & (mask >> 1), c, s);
-        }
+        // harmonic k = m * 2^v: generator of PHASE_WIDTH - v at phase (m*n) mod 2^(PW-v)  (k = 2: bh_win_3term.vhd:221-226)
+        const uint32_t v = (uint32_t)__builtin_ctz(k);
+        taylor_full(taylor_gen(t, v), ((k * n) & mask) >> v, c, s);
         combine_term(acc, win.aa[k], c, k, t.dat_width, win.combine);
     }
     emit(win, out, i, combine_final(acc, t.dat_width, win.combine, win.n_terms));
@@ -1204,16 +1228,24 @@ int bhwk_taylor_window_fold(const BhwLaunch &l, const BhwTaylorCfg &t, const Bhw
         if (fast) hipLaunchKernelGGL((k_taylor_window_fold<NARROW, COMBINE, NT, true>), grid, dim3(kBlock), 0, st, t, w, d_out);  \
         else      hipLaunchKernelGGL((k_taylor_window_fold<NARROW, COMBINE, NT, false>), grid, dim3(kBlock), 0, st, t, w, d_out); \
     } while (0)
-    const bool vhdl = w.combine == BHW_COMBINE_VHDL, three = w.n_terms > 2;
-    const bool fast = (1u << t.lut_size) <= (uint32_t)kTaylorRomLds && t.mode == 2u &&
-                      (!three || (int)t.phi_width - 1 - (int)t.lut_size > 2);
-    if (narrow) {
-        if (vhdl) { if (three) BHW_TAYLOR_FOLD(true, BHW_COMBINE_VHDL, 3); else BHW_TAYLOR_FOLD(true, BHW_COMBINE_VHDL, 2); }
-        else      { if (three) BHW_TAYLOR_FOLD(true, BHW_COMBINE_HLS, 3);  else BHW_TAYLOR_FOLD(true, BHW_COMBINE_HLS, 2); }
-    } else {
-        if (vhdl) { if (three) BHW_TAYLOR_FOLD(false, BHW_COMBINE_VHDL, 3); else BHW_TAYLOR_FOLD(false, BHW_COMBINE_VHDL, 2); }
-        else      { if (three) BHW_TAYLOR_FOLD(false, BHW_COMBINE_HLS, 3);  else BHW_TAYLOR_FOLD(false, BHW_COMBINE_HLS, 2); }
+    const bool vhdl = w.combine == BHW_COMBINE_VHDL;
+    // every generator in use (PHASE_WIDTH - v, v <= vmax) on the 1st-order-correction path, ROM in LDS
+    const int vmax = w.n_terms > 4 ? 2 : w.n_terms > 2 ? 1 : 0;
+    const bool fast = (1u << t.lut_size) <= (uint32_t)kTaylorRomLds && (int)t.phi_width - vmax - (int)t.lut_size > 2;
+#define BHW_TAYLOR_FOLD_NT(NT)                                                                                      \
+    do {                                                                                                            \
+        if (narrow) { if (vhdl) BHW_TAYLOR_FOLD(true, BHW_COMBINE_VHDL, NT);  else BHW_TAYLOR_FOLD(true, BHW_COMBINE_HLS, NT); }  \
+        else        { if (vhdl) BHW_TAYLOR_FOLD(false, BHW_COMBINE_VHDL, NT); else BHW_TAYLOR_FOLD(false, BHW_COMBINE_HLS, NT); } \
+    } while (0)
+    switch (w.n_terms) {
+    case 2: BHW_TAYLOR_FOLD_NT(2); break;
+    case 3: BHW_TAYLOR_FOLD_NT(3); break;
+    case 4: BHW_TAYLOR_FOLD_NT(4); break;
+    case 5: BHW_TAYLOR_FOLD_NT(5); break;
+    case 7: BHW_TAYLOR_FOLD_NT(7); break;
+    default: return (int)hipErrorInvalidValue;
     }
+#undef BHW_TAYLOR_FOLD_NT
 #undef BHW_TAYLOR_FOLD
     return finish(hipSuccess);
 }

@@ -129,16 +129,27 @@ class WinSelector:
                  XSERIES="ULTRA", aa=None, model=B.MODEL_HLS, combine=B.COMBINE_HLS, precision=1, device=None):
         if WIN_TYPE not in _WIN_TYPES:
             raise ValueError(f"WIN_TYPE {WIN_TYPE!r}: expected one of {sorted(_WIN_TYPES)}")
-        if SIN_TYPE not in ("CORDIC", "TAYLOR"):
-            raise ValueError("SIN_TYPE must be 'CORDIC' or 'TAYLOR'")
+        if SIN_TYPE not in ("CORDIC", "TAYLOR", "TAYLOR_ALL"):
+            raise ValueError("SIN_TYPE must be 'CORDIC' or 'TAYLOR' (or this library's extension 'TAYLOR_ALL')")
         if XSERIES not in ("7SERIES", "ULTRA"):  # selects DSP48 port widths only (tay1_order.vhd:538-578)
             raise ValueError("XSERIES must be '7SERIES' or 'ULTRA'")
         self.device = device
         self.params = B.make_params(
             _WIN_TYPES[WIN_TYPE], PHI_WIDTH, DAT_WIDTH, model=model, combine=combine,
-            sin_type=B.SIN_TAYLOR if SIN_TYPE == "TAYLOR" else B.SIN_CORDIC,
+            sin_type=self._sin_type(SIN_TYPE, _WIN_TYPES[WIN_TYPE]),
             precision=precision, lut_size=LUT_SIZE, aa=aa)
         self._phase = 0  # the PHI_WIDTH-bit counter (RESET clears it: bh_win_7term.vhd:179-186)
+
+    @staticmethod
+    def _sin_type(SIN_TYPE, win_type):
+        """The selector hands SIN_TYPE only to hamming_win and bh_win_3term (src/win_selector.vhd:93-135); the 4/5/7-term
+        entities have no such generic (:137-199), so "TAYLOR" there still elaborates the CORDIC design.  "TAYLOR_ALL" is
+        the extension of include/bhw.h (Taylor source for every term count)."""
+        if SIN_TYPE == "TAYLOR_ALL":
+            return B.SIN_TAYLOR_ALL
+        if SIN_TYPE == "TAYLOR" and win_type in (1, 2, 3):
+            return B.SIN_TAYLOR
+        return B.SIN_CORDIC
 
     @property
     def length(self):

@@ -41,8 +41,14 @@ enum {
     BHW_COMBINE_HLS  = 0, /* truncating shift, no rounding: hls/windows/win_function.cpp:168-377 */
     BHW_COMBINE_VHDL = 1  /* per-product round + final round: src/bh_win_7term.vhd:353-438 etc.  */
 };
-/* SIN_TYPE generic of win_selector (src/win_selector.vhd:66). */
-enum { BHW_SIN_CORDIC = 0, BHW_SIN_TAYLOR = 1 };
+/* SIN_TYPE generic of win_selector (src/win_selector.vhd:66).  The reference wires the Taylor source only into the
+ * 2- and 3-term windows (src/win_selector.vhd:93-135; the BH4/5/7 entities take no SIN_TYPE, :137-199), so
+ * BHW_SIN_TAYLOR with more terms is BHW_ERR_UNSUPPORTED here and the win_selector mirrors fall back to CORDIC exactly as
+ * the reference's selector does.  BHW_SIN_TAYLOR_ALL is this library's extension: harmonic
+ * k = m * 2^v (m odd) is read from a taylor_sincos generator of PHASE_WIDTH - v at phase (m * n) mod 2^(PHASE_WIDTH - v)
+ * -- the rule bh_win_3term.vhd:221-226 applies to its 2nd harmonic, continued to k = 3..6.  For 2 and 3 terms it is
+ * identical to BHW_SIN_TAYLOR; for more terms no reference output exists (the oracle defines it). */
+enum { BHW_SIN_CORDIC = 0, BHW_SIN_TAYLOR = 1, BHW_SIN_TAYLOR_ALL = 2 };
 /* win_type codes of win_function() (hls/windows/win_function.cpp:391-420). */
 enum { BHW_WIN_HAMMING = 1, BHW_WIN_HANN = 2, BHW_WIN_BH3 = 3, BHW_WIN_BH4 = 4, BHW_WIN_BH5 = 5, BHW_WIN_BH7 = 7 };
 /* Execution strategy (results are bit-identical across strategies). */

@@ -44,7 +44,10 @@ public:
         if (XSERIES != "ULTRA" && XSERIES != "7SERIES") throw error(BHW_ERR_BADARG, "XSERIES " + XSERIES);
         int rc = bhw_params_init(&p_, wt, PHI_WIDTH, DAT_WIDTH);
         if (rc != BHW_OK && p_.n_terms == 0) check(rc);
-        if (SIN_TYPE == "TAYLOR") p_.sin_type = BHW_SIN_TAYLOR;
+        // SIN_TYPE reaches only hamming_win and bh_win_3term (src/win_selector.vhd:93-135); the 4/5/7-term entities have
+        // no such generic (:137-199), so "TAYLOR" there is still the CORDIC design.  "TAYLOR_ALL": extension, see bhw.h.
+        if (SIN_TYPE == "TAYLOR_ALL") p_.sin_type = BHW_SIN_TAYLOR_ALL;
+        else if (SIN_TYPE == "TAYLOR") p_.sin_type = (p_.n_terms <= 3) ? BHW_SIN_TAYLOR : BHW_SIN_CORDIC;
         else if (SIN_TYPE != "CORDIC") throw error(BHW_ERR_BADARG, "SIN_TYPE " + SIN_TYPE);
         p_.lut_size = LUT_SIZE;
         check(bhw_params_validate(&p_));

@@ -293,12 +293,14 @@ int bhwo_coeffs_from_float(uint32_t win_type, uint32_t W, const double *a, int32
 static int64_t feeder_cos(const bhwo_params *p, uint64_t theta, unsigned harmonic)
 {
     int32_t c = 0, s = 0;
-    if (p->sin_type == BHWO_SIN_TAYLOR) {
+    if (p->sin_type != BHWO_SIN_CORDIC) {
         /* bh_win_3term.vhd:221-226: the 2nd harmonic is a second generator with PHASE_WIDTH-1
-         * driven by its own +1 counter, i.e. phase n mod 2^(PW-1) at width PW-1. */
-        unsigned pw = p->phi_width - (harmonic == 2 ? 1u : 0u);
-        uint64_t n = harmonic == 2 ? theta / 2 : theta;
-        bhwo_taylor(pw, p->dat_width, p->lut_size, n, &c, &s);
+         * driven by its own +1 counter, i.e. phase n mod 2^(PW-1) at width PW-1.
+         * Extension (TAYLOR_ALL, no reference counterpart): harmonic k = m * 2^v, m odd, reads a generator of width
+         * PW - v at phase (m*n) mod 2^(PW-v) = theta >> v; for k <= 2 that is the reference's wiring. */
+        unsigned v = 0;
+        while (!((harmonic >> v) & 1u)) ++v;
+        bhwo_taylor(p->phi_width - v, p->dat_width, p->lut_size, theta >> v, &c, &s);
     } else {
         bhwo_cordic(p->model, p->phi_width, p->dat_width, p->precision, theta, &c, &s, NULL);
     }
@@ -341,9 +343,9 @@ static int params_ok(const bhwo_params *p)
 {
     if (!p) return 0;
     if (!(p->n_terms == 2 || p->n_terms == 3 || p->n_terms == 4 || p->n_terms == 5 || p->n_terms == 7)) return 0;
-    if (p->combine > BHWO_COMBINE_VHDL || p->sin_type > BHWO_SIN_TAYLOR) return 0;
-    if (p->sin_type == BHWO_SIN_TAYLOR) {
-        if (p->n_terms > 3) return 0;                                /* win_selector.vhd:93-135 */
+    if (p->combine > BHWO_COMBINE_VHDL || p->sin_type > BHWO_SIN_TAYLOR_ALL) return 0;
+    if (p->sin_type != BHWO_SIN_CORDIC) {
+        if (p->n_terms > 3 && p->sin_type == BHWO_SIN_TAYLOR) return 0;   /* win_selector.vhd:93-135 */
         if (p->phi_width < 4 || p->phi_width > 32 || p->dat_width < 4 || p->dat_width > 32) return 0;
         return p->lut_size >= 1 && p->lut_size <= 20;
     }
@@ -364,7 +366,7 @@ int bhwo_sincos(const bhwo_params *p, uint64_t theta0, uint64_t count, int32_t *
     build_tables();
     for (uint64_t i = 0; i < count; ++i) {
         int32_t c, s;
-        int rc = p->sin_type == BHWO_SIN_TAYLOR
+        int rc = p->sin_type != BHWO_SIN_CORDIC
                      ? bhwo_taylor(p->phi_width, p->dat_width, p->lut_size, theta0 + i, &c, &s)
                      : bhwo_cordic(p->model, p->phi_width, p->dat_width, p->precision, theta0 + i, &c, &s, NULL);
         if (rc) return rc;

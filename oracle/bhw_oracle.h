@@ -17,7 +17,7 @@
  *       App. B, produced from the unmodified HLS sources during the survey) +
  *       the reference's own tolerance tests; ap_int.h is absent here, so the
  *       HLS sources are unbuildable in this image.
- *   model C (src/*.vhd), Taylor     : PARITY UNPINNED -- no VHDL simulator;
+ *   model C (src/ .vhd files), Taylor    : PARITY UNPINNED -- no VHDL simulator;
  *       restated from source, checked only against the ideal-window tolerance.
  */
 #ifndef BHW_ORACLE_H
@@ -31,7 +31,7 @@ extern "C" {
 
 enum { BHWO_MODEL_HLS = 0, BHWO_MODEL_CPP = 1, BHWO_MODEL_VHDL = 2 };
 enum { BHWO_COMBINE_HLS = 0, BHWO_COMBINE_VHDL = 1 };
-enum { BHWO_SIN_CORDIC = 0, BHWO_SIN_TAYLOR = 1 };
+enum { BHWO_SIN_CORDIC = 0, BHWO_SIN_TAYLOR = 1, BHWO_SIN_TAYLOR_ALL = 2 /* extension: see include/bhw.h */ };
 
 typedef struct {
     uint32_t model;      /* CORDIC bit-model: HLS (B), CPP (A), VHDL (C)     */

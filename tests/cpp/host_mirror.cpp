@@ -39,7 +39,12 @@ int main(int argc, char **argv)
             int bad = 0;
             try { bhw::win_selector s(10, 16, "KAISER"); } catch (const bhw::error &e) { bad += e.code == BHW_ERR_BADARG; }
             try { bhw::win_selector s(26, 16, "BH4TERM"); } catch (const bhw::error &e) { bad += e.code == BHW_ERR_UNSUPPORTED; }
-            try { bhw::win_selector s(12, 16, "BH4TERM", "TAYLOR"); } catch (const bhw::error &e) { bad += e.code == BHW_ERR_UNSUPPORTED; }
+            {   // the selector hands SIN_TYPE only to the 2-/3-term entities (src/win_selector.vhd:137-199): BH4 stays CORDIC
+                bhw::win_selector s(12, 16, "BH4TERM", "TAYLOR");
+                bhw_params raw = s.params();
+                raw.sin_type = BHW_SIN_TAYLOR;                 // the ABI itself refuses what the reference cannot build
+                bad += (s.params().sin_type == BHW_SIN_CORDIC && bhw_params_validate(&raw) == BHW_ERR_UNSUPPORTED);
+            }
             auto z = bhw::win_function(6, 0, 8, 10, 16);   // unknown selector -> win_empty
             for (int32_t v : z) bad += (v == 0) ? 0 : 100;
             printf("%d\n", bad);

@@ -15,7 +15,7 @@ REF_DIR = os.path.join(ROOT, "oracle", "_ref")
 
 MODEL_HLS, MODEL_CPP, MODEL_VHDL = 0, 1, 2
 COMBINE_HLS, COMBINE_VHDL = 0, 1
-SIN_CORDIC, SIN_TAYLOR = 0, 1
+SIN_CORDIC, SIN_TAYLOR, SIN_TAYLOR_ALL = 0, 1, 2
 TERMS = {1: 2, 2: 2, 3: 3, 4: 4, 5: 5, 7: 7}
 
 
@@ -91,6 +91,19 @@ def sincos(p, theta0, count):
     if rc:
         raise ValueError("oracle rejected the parameters")
     return s, c
+
+
+def taylor(phi_width, dat_width, lut_size, phases):
+    """taylor_sincos generator swept over `phases` (any integer array): returns (cos, sin)."""
+    o = oracle()
+    c1 = np.empty(1, np.int32)
+    s1 = np.empty(1, np.int32)
+    c = np.empty(len(phases), np.int32)
+    s = np.empty(len(phases), np.int32)
+    for i, t in enumerate(phases):
+        assert o.bhwo_taylor(phi_width, dat_width, lut_size, int(t), c1.ctypes.data, s1.ctypes.data) == 0
+        c[i], s[i] = c1[0], s1[0]
+    return c, s
 
 
 def coeffs(win_type, dat_width, a=None):

@@ -94,6 +94,13 @@ def test_validation_errors():
     assert _rc(p) == 0
     p.phi_width = 30                                   # STAGE = 18 > 15
     assert _rc(p) == -2
+    # the extension: Taylor source for every term count; generator widths PW, PW-1, PW-2 must all exist
+    p = B.make_params(B.WIN_BH7, 12, 16, sin_type=B.SIN_TAYLOR_ALL, lut_size=9)
+    assert _rc(p) == 0
+    p.phi_width = 4
+    assert _rc(p) == -2
+    p.sin_type = 3
+    assert _rc(p) == -1
 
 
 def test_compute_entry_points_fail_loudly_without_gpu():

@@ -60,6 +60,63 @@ def test_golden_taylor(torch, golden, golden_dir, name):
     assert _md5(got) == e["md5"]
 
 
+# Taylor source: reference wiring (2-/3-term) and the all-term-count extension (BHW_SIN_TAYLOR_ALL, include/bhw.h).
+# (win, pw, w, lut_size): generator modes PW-L < 2 / == 2 / > 2 for every generator width PW-v in use, narrow (W < 19)
+# and wide rounding variants, int32 fast path (W <= 16), ROM in LDS and beyond it (L = 13).
+TAYLOR_CASES = [(1, 12, 16, 9), (2, 10, 16, 9), (3, 14, 24, 9), (3, 11, 16, 9), (3, 12, 18, 10), (1, 8, 12, 9),
+                (3, 10, 20, 9), (1, 16, 32, 9), (3, 16, 31, 11), (3, 17, 16, 13), (1, 18, 24, 4),
+                (4, 12, 16, 9), (4, 14, 24, 9), (5, 13, 16, 9), (5, 15, 32, 9), (7, 14, 16, 9), (7, 16, 32, 9),
+                (7, 12, 24, 9), (7, 11, 30, 9), (7, 13, 18, 10), (5, 10, 20, 9), (7, 17, 16, 13), (4, 18, 30, 12),
+                (7, 5, 16, 2), (5, 6, 12, 3), (7, 18, 19, 6)]
+
+
+@pytest.mark.parametrize("combine", [B.COMBINE_HLS, B.COMBINE_VHDL])
+@pytest.mark.parametrize("win,pw,w,L", TAYLOR_CASES)
+def test_taylor_window_matches_oracle(torch, win, pw, w, L, combine):
+    sin_type = B.SIN_TAYLOR if win <= 3 else B.SIN_TAYLOR_ALL
+    p = B.make_params(win, pw, w, combine=combine, sin_type=sin_type, lut_size=L)
+    n = 1 << pw
+    op = O.from_bhw(p)
+    # whole period(s) + ragged ends: fold kernel for the periods, general kernel for head and tail
+    n0, count = (n - 37, 2 * n + 91) if pw <= 14 else (0, n)
+    got = gpu_generate(p, n0, count)
+    if pw <= 14:
+        assert np.array_equal(got, O.generate(op, n0, count))
+    else:
+        rng = np.random.default_rng(pw * 100 + w)
+        idx = np.unique(np.concatenate([np.arange(300), n // 4 + np.arange(-150, 150), n // 2 + np.arange(-150, 150),
+                                        3 * (n // 4) + np.arange(-150, 150), n - 1 - np.arange(300),
+                                        n // 8 + np.arange(-50, 50), n // 16 * 3 + np.arange(-50, 50),
+                                        rng.integers(0, n, 1500)]))
+        want = np.array([O.generate(op, int(i), 1)[0] for i in idx], dtype=np.int32)
+        assert np.array_equal(got[idx], want)
+        # ragged call into the middle of the period: general kernel
+        mid = gpu_generate(p, n // 3, 1000)
+        assert np.array_equal(mid, got[n // 3:n // 3 + 1000])
+
+
+def test_taylor_all_equals_reference_wiring_for_2_and_3_terms(torch):
+    for win, pw, w in [(1, 13, 16), (3, 13, 24), (3, 16, 32)]:
+        a = gpu_generate(B.make_params(win, pw, w, sin_type=B.SIN_TAYLOR, lut_size=9), 0, 1 << pw)
+        b = gpu_generate(B.make_params(win, pw, w, sin_type=B.SIN_TAYLOR_ALL, lut_size=9), 0, 1 << pw)
+        assert np.array_equal(a, b)
+
+
+def test_win_selector_ignores_taylor_for_4_5_7_terms_like_the_reference(torch):
+    """src/win_selector.vhd:137-199: the BH4/5/7 entities take no SIN_TYPE, the selector elaborates CORDIC."""
+    import blackman_harris_win_amd as bhw
+    a = bhw.WinSelector(PHI_WIDTH=12, DAT_WIDTH=24, WIN_TYPE="BH7TERM", SIN_TYPE="TAYLOR").window()
+    b = bhw.WinSelector(PHI_WIDTH=12, DAT_WIDTH=24, WIN_TYPE="BH7TERM", SIN_TYPE="CORDIC").window()
+    assert bool((a == b).all())
+    # the extension with the VHDL cosine-sum (full-scale cosines, halved products, final /4: bh_win_7term.vhd:353-438):
+    # DT_WIN = (A0 - A1 cos x + A2 cos 2x - ...) / 4 within a few LSB
+    sel = bhw.WinSelector(PHI_WIDTH=12, DAT_WIDTH=24, WIN_TYPE="BH7TERM", SIN_TYPE="TAYLOR_ALL", combine=B.COMBINE_VHDL)
+    c = sel.window().cpu().numpy().astype(np.float64)
+    x = 2 * np.pi * np.arange(1 << 12) / (1 << 12)
+    ideal = sum((-1) ** k * sel.params.aa[k] * np.cos(k * x) for k in range(7)) / 4
+    assert np.abs(c - ideal).max() < 12
+
+
 def test_golden_reference_sincos(torch, golden, golden_dir):
     """GPU cordic() vs vectors produced by the reference's own compiled cordic() (model CPP)."""
     import blackman_harris_win_amd as bhw

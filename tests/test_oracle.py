@@ -178,6 +178,34 @@ def test_taylor_close_to_float():
         assert np.abs(c - amp * np.cos(2 * math.pi * i / n)).max() <= tol
 
 
+def test_taylor_all_extension():
+    """BHW_SIN_TAYLOR_ALL (include/bhw.h): identical to the reference wiring for 2/3 terms; for 4/5/7 terms the harmonic
+    k = m*2^v comes from the PHASE_WIDTH-v generator, and the window stays within a few LSB of the ideal one."""
+    for win, pw, w in [(1, 11, 16), (3, 12, 24)]:
+        a = O.generate(O.oparams(win, pw, w, sin_type=O.SIN_TAYLOR, lut_size=9), 0, 1 << pw)
+        b = O.generate(O.oparams(win, pw, w, sin_type=O.SIN_TAYLOR_ALL, lut_size=9), 0, 1 << pw)
+        assert np.array_equal(a, b)
+    coe = {4: [0.35875, 0.48829, 0.14128, 0.01168],
+           7: [0.271220360585039, 0.433444612327442, 0.218004122892930, 0.065785343295606, 0.010761867305342,
+               0.000770012710581, 0.000013680883060]}
+    for win, pw, w in [(4, 12, 16), (7, 13, 24), (7, 12, 32)]:
+        n = 1 << pw
+        p = O.oparams(win, pw, w, sin_type=O.SIN_TAYLOR_ALL, lut_size=9)
+        got = O.generate(p, 0, n).astype(np.float64)
+        x = 2 * math.pi * np.arange(n) / n
+        # weights a_k scale to 2^(W-s)-1, cosines to 2^(W-1)-1, products >> (W-2): unit = 2 * a_k * cos
+        amp = 2.0 ** (w - 1) - 1
+        ideal = sum((-1) ** k * p.aa[k] * (np.cos(k * x) * amp if k else 2.0 ** (w - 2)) for k in range(len(coe[win]))) / 2.0 ** (w - 2)
+        # 1st-order Taylor error per harmonic ~ amp * (pi / 2^(L+1))^2 / 2 relative to full scale, plus truncations
+        tol = 8 + sum(abs(p.aa[k]) for k in range(1, len(coe[win]))) / 2.0 ** (w - 2) * (amp * (math.pi / 2 ** 10) ** 2 / 2 + 2)
+        err = (got - ideal + 2.0 ** (w - 1)) % 2.0 ** w - 2.0 ** (w - 1)      # s = 1 windows wrap at their peak, like the HLS model
+        assert np.abs(err).max() <= tol, (win, pw, w, np.abs(err).max(), tol)
+        # the 4th harmonic really is the PHASE_WIDTH-2 generator: cos of harmonic 4 at n equals generator(PW-2) at n mod N/4
+        c4, _ = O.taylor(pw - 2, w, 9, np.arange(n) % (n // 4))
+        c1, _ = O.taylor(pw, w, 9, (4 * np.arange(n)) % n)
+        assert np.abs(c4.astype(np.int64) - c1).max() <= 8      # same angle, different rounding path
+
+
 # ---- structural facts the kernels rely on -----------------------------------------------------------
 def test_typed_store_wraps_never_fire():
     """The W+2 / W+P bit wraps of the HLS/VHDL CORDIC never change a value (kernels omit them)."""
@@ -224,4 +252,5 @@ def test_oracle_rejects_bad_params():
     with pytest.raises(ValueError):
         O.generate(O.oparams(4, 10, 16, n_terms=6), 0, 4)
     with pytest.raises(ValueError):
-        O.generate(O.oparams(5, 10, 16, sin_type=O.SIN_TAYLOR), 0, 4)
+        O.generate(O.oparams(5, 10, 16, sin_type=O.SIN_TAYLOR), 0, 4)   # reference wiring: 2-/3-term only
+    assert len(O.generate(O.oparams(5, 10, 16, sin_type=O.SIN_TAYLOR_ALL), 0, 4)) == 4
