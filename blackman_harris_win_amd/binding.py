@@ -4,7 +4,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-MODEL_HLS, MODEL_CPP, MODEL_VHDL = 0, 1, 2
+MODEL_HLS, MODEL_CPP, MODEL_VHDL, MODEL_DDS48, MODEL_SCALED = 0, 1, 2, 3, 4
 COMBINE_HLS, COMBINE_VHDL = 0, 1
 SIN_CORDIC, SIN_TAYLOR, SIN_TAYLOR_ALL = 0, 1, 2
 WIN_HAMMING, WIN_HANN, WIN_BH3, WIN_BH4, WIN_BH5, WIN_BH7 = 1, 2, 3, 4, 5, 7
@@ -15,7 +15,7 @@ ABI_SYMBOLS = (
     "bhw_abi_version", "bhw_strerror", "bhw_last_error", "bhw_params_init", "bhw_params_validate",
     "bhw_coeffs_from_float", "bhw_constant_tables", "bhw_generate_device", "bhw_generate_device_ex",
     "bhw_workspace_bytes", "bhw_generate_batched_device", "bhw_sincos_device", "bhw_generate_to_host",
-    "bhw_sincos_to_host", "bhw_release_device", "bhw_apply_device",
+    "bhw_sincos_to_host", "bhw_release_device", "bhw_apply_device", "bhw_atan2_device", "bhw_atan2_to_host",
 )
 
 
@@ -34,6 +34,12 @@ class BhwParams(ctypes.Structure):
         ("phi_width", ctypes.c_uint32), ("dat_width", ctypes.c_uint32), ("precision", ctypes.c_uint32),
         ("lut_size", ctypes.c_uint32), ("aa", ctypes.c_int32 * 7),
     ]
+
+
+class BhwAtan2Params(ctypes.Structure):
+    """struct bhw_atan2_params of include/bhw.h (generics of entity cordic_atan2, src/cordic_atan2.vhd:64-69)."""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("precision", ctypes.c_uint32),
+                ("input_width", ctypes.c_uint32), ("angle_width", ctypes.c_uint32)]
 
 
 class BhwExec(ctypes.Structure):
@@ -87,6 +93,9 @@ def lib():
     L.bhw_sincos_to_host.argtypes = [P, ci, u64, u64, i32p, i32p]
     L.bhw_release_device.argtypes = [ci]
     L.bhw_apply_device.argtypes = [P, ci, vp, u64, u64, i32p, i32p, u32]
+    PA = ctypes.POINTER(BhwAtan2Params)
+    L.bhw_atan2_device.argtypes = [PA, ci, vp, u64, i32p, i32p, i32p]
+    L.bhw_atan2_to_host.argtypes = [PA, ci, u64, i32p, i32p, i32p]
     _lib = L
     return L
 
@@ -129,6 +138,7 @@ def make_params(win_type, phi_width, dat_width, *, model=MODEL_HLS, combine=COMB
         vals = list(aa) + [0] * (7 - len(aa))
         for k in range(7):
             p.aa[k] = int(vals[k])
-    if validate:
+    # the variant generators (cordic_dds48 / cordic_dds_scaled) are sin/cos sources only: bhw_sincos_* validates them
+    if validate and model <= MODEL_VHDL:
         check(lib().bhw_params_validate(ctypes.byref(p)))
     return p

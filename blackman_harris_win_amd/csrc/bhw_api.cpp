@@ -66,12 +66,17 @@ const double kBh5[5] = {0.3232153788877343, 0.4714921439576260, 0.17553412996019
 const double kBh7[7] = {0.271220360585039, 0.433444612327442, 0.218004122892930, 0.065785343295606,
                         0.010761867305342, 0.000770012710581, 0.000013680883060};
 
-int validate(const bhw_params *p)
+const uint32_t kSelSize[25] = {15, 15, 15, 18, 21, 22, 23, 26, 30, 31, 32, 33,           // src/cordic_dds_scaled.vhd:102-107
+                               38, 38, 38, 42, 42, 45, 47, 47, 47, 48, 48, 48, 48};
+
+int validate(const bhw_params *p, bool sincos_only = false)
 {
     if (!p) return fail(BHW_ERR_BADARG, "params is NULL");
     if (p->struct_size != sizeof(bhw_params))
         return fail(BHW_ERR_BADARG, "struct_size %u != %zu", p->struct_size, sizeof(bhw_params));
-    if (p->model > BHW_MODEL_VHDL) return fail(BHW_ERR_BADARG, "model %u", p->model);
+    if (p->model > BHW_MODEL_SCALED) return fail(BHW_ERR_BADARG, "model %u", p->model);
+    if (p->model > BHW_MODEL_VHDL && !sincos_only)
+        return fail(BHW_ERR_UNSUPPORTED, "cordic_dds48 / cordic_dds_scaled feed no window entity: bhw_sincos_* only");
     if (p->combine > BHW_COMBINE_VHDL) return fail(BHW_ERR_BADARG, "combine %u", p->combine);
     if (p->sin_type > BHW_SIN_TAYLOR_ALL) return fail(BHW_ERR_BADARG, "sin_type %u", p->sin_type);
     const uint32_t K = p->n_terms;
@@ -481,7 +486,7 @@ int bhw_generate_batched_device(const bhw_params *p, int device, void *hip_strea
 int bhw_sincos_device(const bhw_params *p, int device, void *hip_stream, uint64_t theta0, uint64_t count,
                       int32_t *d_sin, int32_t *d_cos)
 {
-    int rc = validate(p);
+    int rc = validate(p, true);
     if (rc) return rc;
     if (!count) return BHW_OK;
     if (!d_sin && !d_cos) return fail(BHW_ERR_BADARG, "both outputs NULL");
@@ -493,6 +498,20 @@ int bhw_sincos_device(const bhw_params *p, int device, void *hip_stream, uint64_
         if (rc) return rc;
         int e = bhwk_taylor_sincos(l, t, theta0, count, d_sin, d_cos);
         return e ? fail_hip(e, "taylor sincos launch") : BHW_OK;
+    }
+    if (p->model > BHW_MODEL_VHDL) {
+        // cordic_dds48: SIZE = DWPH = 48 (src/cordic_dds48.vhd:143-153); cordic_dds_scaled: SIZE = SEL_SIZE(DATA_WIDTH-8),
+        // DWPH = max(SIZE, PHASE_WIDTH) (src/cordic_dds_scaled.vhd:109,133-143)
+        BhwPrerotCfg c;
+        memset(&c, 0, sizeof c);
+        c.phi_width = p->phi_width;
+        c.dat_width = p->dat_width;
+        c.size = p->model == BHW_MODEL_DDS48 ? 48u : kSelSize[p->dat_width - 8];
+        c.dwph = c.size < p->phi_width ? p->phi_width : c.size;
+        c.gain = kGain46 >> (48 - c.size);                                          // GAIN48(47 downto 48-SIZE)
+        for (uint32_t i = 0; i + 1 < p->dat_width; ++i) c.lut[i] = kAtanT2[i] >> (48 - c.dwph);   // ROM_LUT(ii)(47 downto 48-DWPH)
+        int e = bhwk_sincos_prerot(l, c, theta0, count, d_sin, d_cos);
+        return e ? fail_hip(e, "sincos (pre-rotated) launch") : BHW_OK;
     }
     BhwCordicCfg c;
     resolve_cordic(p, c);
@@ -523,7 +542,7 @@ int bhw_generate_to_host(const bhw_params *p, int device, uint64_t n0, uint64_t 
 
 int bhw_sincos_to_host(const bhw_params *p, int device, uint64_t theta0, uint64_t count, int32_t *h_sin, int32_t *h_cos)
 {
-    int rc = validate(p);
+    int rc = validate(p, true);
     if (rc) return rc;
     if (!count) return BHW_OK;
     if (!h_sin && !h_cos) return fail(BHW_ERR_BADARG, "both outputs NULL");
@@ -573,6 +592,63 @@ int bhw_dbg_table_combine(const bhw_params *p, int device, void *stream, const v
         return bhwk_table_combine_tile(l, c, w, (const int32_t *)ws, d_out);
     }
     return bhwk_table_combine_fold(l, c, w, (const int32_t *)ws, d_out);
+}
+
+static int validate_atan2(const bhw_atan2_params *p)
+{
+    if (!p) return fail(BHW_ERR_BADARG, "params is NULL");
+    if (p->struct_size != sizeof(bhw_atan2_params))
+        return fail(BHW_ERR_BADARG, "struct_size %u != %zu", p->struct_size, sizeof(bhw_atan2_params));
+    if (p->precision < 1 || p->precision > 7) return fail(BHW_ERR_BADARG, "precision %u outside 1..7", p->precision);
+    if (p->angle_width < 4 || p->angle_width > 32) return fail(BHW_ERR_BADARG, "angle_width %u outside 4..32", p->angle_width);
+    if (p->input_width > 32) return fail(BHW_ERR_BADARG, "input_width %u > 32", p->input_width);
+    if (p->input_width + 1 < p->angle_width)   // VEC_DX(ii) for ii = 0 .. ANGLE_WIDTH-2: src/cordic_atan2.vhd:142-145
+        return fail(BHW_ERR_UNSUPPORTED, "input_width %u < angle_width-1: the entity indexes input bits 0..ANGLE_WIDTH-2", p->input_width);
+    return BHW_OK;
+}
+
+int bhw_atan2_device(const bhw_atan2_params *p, int device, void *hip_stream, uint64_t count,
+                     const int32_t *d_x, const int32_t *d_y, int32_t *d_phi)
+{
+    int rc = validate_atan2(p);
+    if (rc) return rc;
+    if (!count) return BHW_OK;
+    if (!d_x || !d_y || !d_phi) return fail(BHW_ERR_BADARG, "d_x / d_y / d_phi is NULL");
+    if (!device_ok(device)) return fail(BHW_ERR_HIP, "no usable HIP device %d (this library has no CPU path)", device);
+    BhwAtan2Cfg c;
+    memset(&c, 0, sizeof c);
+    c.precision = p->precision;
+    c.input_width = p->input_width;
+    c.angle_width = p->angle_width;
+    const uint32_t B = p->angle_width + p->precision;
+    for (uint32_t i = 0; i + 1 < p->angle_width; ++i) c.lut[i] = kAtanT4[i] >> (49 - B);   // src/cordic_atan2.vhd:100-103
+    BhwLaunch l{device, hip_stream};
+    int e = bhwk_atan2(l, c, count, d_x, d_y, d_phi);
+    return e ? fail_hip(e, "atan2 launch") : BHW_OK;
+}
+
+int bhw_atan2_to_host(const bhw_atan2_params *p, int device, uint64_t count, const int32_t *h_x, const int32_t *h_y, int32_t *h_phi)
+{
+    int rc = validate_atan2(p);
+    if (rc) return rc;
+    if (!count) return BHW_OK;
+    if (!h_x || !h_y || !h_phi) return fail(BHW_ERR_BADARG, "h_x / h_y / h_phi is NULL");
+    if (!device_ok(device)) return fail(BHW_ERR_HIP, "no usable HIP device %d (this library has no CPU path)", device);
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+    int32_t *d = nullptr;
+    e = hipMalloc((void **)&d, 3 * count * sizeof(int32_t));
+    if (e != hipSuccess) return fail_hip(e, "hipMalloc(atan2)");
+    e = hipMemcpy(d, h_x, count * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + count, h_y, count * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = fail_hip(e, "hipMemcpy(H2D)");
+    if (!rc) rc = bhw_atan2_device(p, device, nullptr, count, d, d + count, d + 2 * count);
+    if (!rc) {
+        e = hipMemcpy(h_phi, d + 2 * count, count * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail_hip(e, "hipMemcpy(D2H)");
+    }
+    (void)hipFree(d);
+    return rc;
 }
 
 int bhw_release_device(int device)

@@ -47,6 +47,17 @@ struct BhwTaylorCfg {
     uint32_t pad[2];
 };
 
+// cordic_dds48 / cordic_dds_scaled (quadrant folded into the start vector) and cordic_atan2
+struct BhwPrerotCfg {
+    int64_t  lut[32];     // T2[i] >> (48 - DWPH)
+    int64_t  gain;        // GAIN48 >> (48 - SIZE)
+    uint32_t phi_width, dat_width, size, dwph;
+};
+struct BhwAtan2Cfg {
+    int64_t  lut[32];     // T4[i] >> (49 - (ANGLE_WIDTH + PRECISION))
+    uint32_t precision, input_width, angle_width, pad;
+};
+
 struct BhwLaunch {
     int   device;
     void *stream;
@@ -57,6 +68,9 @@ int bhwk_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w,
                 uint64_t n0, uint64_t count, int32_t *d_out);
 int bhwk_sincos(const BhwLaunch &l, const BhwCordicCfg &c, uint64_t theta0, uint64_t count,
                 int32_t *d_sin, int32_t *d_cos);
+int bhwk_sincos_prerot(const BhwLaunch &l, const BhwPrerotCfg &c, uint64_t theta0, uint64_t count,
+                       int32_t *d_sin, int32_t *d_cos);
+int bhwk_atan2(const BhwLaunch &l, const BhwAtan2Cfg &c, uint64_t count, const int32_t *d_x, const int32_t *d_y, int32_t *d_phi);
 int bhwk_replicate(const BhwLaunch &l, const int32_t *d_frame, uint64_t frame_len, uint32_t frames, int32_t *d_out);
 int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table /* (c,s) pairs, 2^(PW-2) */);
 int bhwk_table_combine(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table,

@@ -1250,6 +1250,79 @@ int bhwk_taylor_window_fold(const BhwLaunch &l, const BhwTaylorCfg &t, const Bhw
     return finish(hipSuccess);
 }
 
+// ---------------------------------------------------------------------------------------
+// Variant generators.  One lane per sample, 64-bit state wrapped to the entity's vector widths.
+// ---------------------------------------------------------------------------------------
+// cordic_dds48 (src/cordic_dds48.vhd:160-258) and cordic_dds_scaled (src/cordic_dds_scaled.vhd:176-283)
+__global__ __launch_bounds__(kBlock) void k_sincos_prerot(BhwPrerotCfg c, uint64_t theta0, uint64_t count,
+                                                           int32_t *__restrict__ d_sin, int32_t *__restrict__ d_cos)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t PW = c.phi_width, W = c.dat_width;
+    const uint64_t theta = (theta0 + i) & ((1ull << PW) - 1ull);
+    const uint32_t q = (uint32_t)(theta >> (PW - 2)) & 3u;              // dds48 :167
+    const uint64_t low = theta & ((1ull << (PW - 2)) - 1ull);
+    uint64_t t = theta;                                                 // init_t :169-186
+    int64_t x = c.gain, y = 0;                                          // init_x / init_y :191-216
+    if (q == 1u)      { t = low;                      x = 0; y = wrap_bits(-c.gain, c.size); }
+    else if (q == 2u) { t = (3ull << (PW - 2)) | low; x = 0; y = c.gain; }
+    int64_t z = wrap_bits((int64_t)(t << (c.dwph - PW)), c.dwph);       // init_z :163-164 (scaled :180-186)
+    for (uint32_t ii = 0; ii < W; ++ii) {                               // :233-251
+        const int64_t xs = x >> ii, ys = y >> ii;
+        const bool pos = z >= 0;
+        x = wrap_bits(pos ? x + ys : x - ys, c.size);
+        y = wrap_bits(pos ? y - xs : y + xs, c.size);
+        if (ii + 1 < W) z = wrap_bits(pos ? z - c.lut[ii] : z + c.lut[ii], c.dwph);
+    }
+    if (d_sin) d_sin[i] = (int32_t)(y >> (c.size - W));                 // :257-258
+    if (d_cos) d_cos[i] = (int32_t)(x >> (c.size - W));
+}
+
+// cordic_atan2 (src/cordic_atan2.vhd:126-213)
+__global__ __launch_bounds__(kBlock) void k_atan2(BhwAtan2Cfg c, uint64_t count, const int32_t *__restrict__ d_x,
+                                                   const int32_t *__restrict__ d_y, int32_t *__restrict__ d_phi)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t IW = c.input_width, AW = c.angle_width, B = AW + c.precision;
+    const uint64_t im = (IW >= 64) ? ~0ull : ((1ull << IW) - 1ull);
+    const uint64_t ux = (uint64_t)(int64_t)d_x[i] & im, uy = (uint64_t)(int64_t)d_y[i] & im;
+    const uint32_t sx = (uint32_t)(ux >> (IW - 1)) & 1u, sy = (uint32_t)(uy >> (IW - 1)) & 1u;
+    const uint64_t lowm = (1ull << (AW - 1)) - 1ull;
+    int64_t x = (int64_t)((sx ? ~ux : ux) & lowm);                       // :142-147
+    int64_t y = (int64_t)((sy ? ~uy : uy) & lowm);
+    int64_t z = 0;                                                      // :152
+    for (uint32_t ii = 0; ii + 1 < AW; ++ii) {                          // :172-190
+        const int64_t xs = x >> ii, ys = y >> ii;
+        const bool pos = y >= 0;
+        x = wrap_bits(pos ? x + ys : x - ys, B);
+        y = wrap_bits(pos ? y - xs : y + xs, B);
+        z = wrap_bits(pos ? z - c.lut[ii] : z + c.lut[ii], B);
+    }
+    const int64_t phi = wrap_bits(z >> c.precision, AW);                // :194
+    const int64_t pi_word = (int64_t)1 << (AW - 2);                     // PHI_PI :112
+    const uint32_t quad = (sx << 1) | sy;                               // :126-128
+    const int64_t out = quad == 0u ? phi : quad == 1u ? phi + pi_word : quad == 2u ? -phi : phi - pi_word;   // :207-213
+    d_phi[i] = (int32_t)wrap_bits(out, AW);
+}
+
+int bhwk_sincos_prerot(const BhwLaunch &l, const BhwPrerotCfg &c, uint64_t theta0, uint64_t count, int32_t *d_sin, int32_t *d_cos)
+{
+    if (!count) return 0;
+    BHW_SET_DEVICE(l);
+    hipLaunchKernelGGL(k_sincos_prerot, dim3(grid_for(count)), dim3(kBlock), 0, (hipStream_t)l.stream, c, theta0, count, d_sin, d_cos);
+    return finish(hipSuccess);
+}
+
+int bhwk_atan2(const BhwLaunch &l, const BhwAtan2Cfg &c, uint64_t count, const int32_t *d_x, const int32_t *d_y, int32_t *d_phi)
+{
+    if (!count) return 0;
+    BHW_SET_DEVICE(l);
+    hipLaunchKernelGGL(k_atan2, dim3(grid_for(count)), dim3(kBlock), 0, (hipStream_t)l.stream, c, count, d_x, d_y, d_phi);
+    return finish(hipSuccess);
+}
+
 int bhwk_taylor_sincos(const BhwLaunch &l, const BhwTaylorCfg &t, uint64_t theta0, uint64_t count, int32_t *d_sin, int32_t *d_cos)
 {
     if (!count) return 0;

@@ -107,6 +107,25 @@ def cordic(params, theta0, count, *, device=None):
     return s, c
 
 
+def atan2(x, y, *, PRECISION=1, INPUT_WIDTH=20, ANGLE_WIDTH=16, out=None):
+    """entity cordic_atan2 (src/cordic_atan2.vhd:64-76) over int32 CUDA tensors VEC_DX = x, VEC_DY = y: returns PHI_DT
+    (ANGLE_WIDTH-bit words, sign-extended; full circle = 2^ANGLE_WIDTH) via bhw_atan2_device."""
+    torch = _torch()
+    if x.dtype != torch.int32 or y.dtype != torch.int32 or not x.is_cuda or x.device != y.device or x.shape != y.shape:
+        raise ValueError("x and y must be int32 CUDA tensors of the same shape on one device")
+    x, y = x.contiguous(), y.contiguous()
+    dev = x.device.index
+    phi = torch.empty_like(x) if out is None else out
+    if phi.dtype != torch.int32 or phi.device != x.device or phi.numel() != x.numel() or not phi.is_contiguous():
+        raise ValueError("out must be a contiguous int32 tensor like x")
+    p = B.BhwAtan2Params(ctypes.sizeof(B.BhwAtan2Params), PRECISION, INPUT_WIDTH, ANGLE_WIDTH)
+    with torch.cuda.device(dev):
+        B.check(B.lib().bhw_atan2_device(ctypes.byref(p), dev, _stream_ptr(torch, dev), x.numel(),
+                                          ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()),
+                                          ctypes.c_void_p(phi.data_ptr())))
+    return phi
+
+
 def win_function(win_type, i0, count, *, nphase, nwidth, device=None, **kw):
     """HLS top function swept over i (hls/windows/win_function.h:65-69): unknown win_type -> zeros
     (win_empty, hls/windows/win_function.cpp:159-165,417-419)."""

@@ -34,7 +34,12 @@ extern "C" {
 enum {
     BHW_MODEL_HLS  = 0,  /* hls/windows/win_function.cpp:47-156 (= hls/cordic/cordic.cpp)   */
     BHW_MODEL_CPP  = 1,  /* cpp/cordic_sincos.cpp:10-92                                      */
-    BHW_MODEL_VHDL = 2   /* src/cordic_dds.vhd:94-249                                        */
+    BHW_MODEL_VHDL = 2,  /* src/cordic_dds.vhd:94-249                                        */
+    /* The two variant generators of the repository: accepted by bhw_sincos_* only (no window entity instantiates them,
+     * so window generation with them is BHW_ERR_UNSUPPORTED).  As written upstream they deliver DT_COS = +cos, DT_SIN = -sin
+     * at amplitude 2^(DATA_WIDTH-2) (x/y update sense of src/cordic_dds48.vhd:234-242). */
+    BHW_MODEL_DDS48  = 3, /* src/cordic_dds48.vhd:94-260: 48-bit data path, quadrant folded into the start vector */
+    BHW_MODEL_SCALED = 4  /* src/cordic_dds_scaled.vhd:98-286: data path SEL_SIZE(DATA_WIDTH-8) bits (:102-107)  */
 };
 /* Cosine-sum rule. */
 enum {
@@ -136,7 +141,8 @@ int bhw_generate_batched_device(const bhw_params *p, int device, void *hip_strea
 
 /* Replaces cordic() alone: cpp/cordic_sincos.cpp:10 (model CPP), hls/cordic/cordic.cpp:45
  * (model HLS), the cordic_dds entity src/cordic_dds.vhd:77-92 (model VHDL), or taylor_sincos
- * src/taylor_sincos.vhd:64-80 (sin_type TAYLOR).  Either output pointer may be NULL. */
+ * src/taylor_sincos.vhd:64-80 (sin_type TAYLOR), cordic_dds48 src/cordic_dds48.vhd:98-112 (model DDS48) or
+ * cordic_dds_scaled src/cordic_dds_scaled.vhd:81-96 (model SCALED).  Either output pointer may be NULL. */
 int bhw_sincos_device(const bhw_params *p, int device, void *hip_stream,
                       uint64_t theta0, uint64_t count, int32_t *d_sin, int32_t *d_cos);
 
@@ -145,6 +151,22 @@ int bhw_sincos_device(const bhw_params *p, int device, void *hip_stream,
 int bhw_generate_to_host(const bhw_params *p, int device, uint64_t n0, uint64_t count, int32_t *h_out);
 int bhw_sincos_to_host(const bhw_params *p, int device, uint64_t theta0, uint64_t count,
                        int32_t *h_sin, int32_t *h_cos);
+
+/* Replaces the cordic_atan2 entity (src/cordic_atan2.vhd:64-76): vectoring CORDIC, one angle per (x, y) pair.
+ * VEC_DX / VEC_DY are INPUT_WIDTH-bit two's-complement words carried in int32; PHI_DT is the ANGLE_WIDTH-bit output word,
+ * sign-extended to int32 (full circle = 2^angle_width; quadrant fix-ups exactly as written at :126-128,:207-213).
+ * The entity reads bits 0..ANGLE_WIDTH-2 of its inputs (:142-145), so input_width >= angle_width - 1 is required
+ * (upstream's default generics 20/24 do not elaborate).  d_x, d_y, d_phi: `count` int32 each; d_phi may alias neither. */
+typedef struct bhw_atan2_params {
+    uint32_t struct_size;   /* sizeof(bhw_atan2_params)                                  */
+    uint32_t precision;     /* 1..7              PRECISION                               */
+    uint32_t input_width;   /* <= 32             INPUT_WIDTH                             */
+    uint32_t angle_width;   /* 4..32             ANGLE_WIDTH                             */
+} bhw_atan2_params;
+int bhw_atan2_device(const bhw_atan2_params *p, int device, void *hip_stream, uint64_t count,
+                     const int32_t *d_x, const int32_t *d_y, int32_t *d_phi);
+int bhw_atan2_to_host(const bhw_atan2_params *p, int device, uint64_t count,
+                      const int32_t *h_x, const int32_t *h_y, int32_t *h_phi);
 
 /* Releases the library-owned per-device scratch. */
 int bhw_release_device(int device);

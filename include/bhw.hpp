@@ -3,7 +3,9 @@
 // The reference is compiled code (VHDL entities + C++ bit-models), so the host side above the ABI is C++:
 //   bhw::win_selector   <->  entity win_selector            src/win_selector.vhd:60-87
 //   bhw::win_function() <->  HLS top win_function()         hls/windows/win_function.h:65-69
-//   bhw::cordic()       <->  cordic()                       cpp/cordic_sincos.cpp:10, hls/cordic/cordic.cpp:45
+//   bhw::cordic()       <->  cordic()                       cpp/cordic_sincos.cpp:10, hls/cordic/cordic.cpp:45;
+//                            entities cordic_dds / cordic_dds48 / cordic_dds_scaled (model BHW_MODEL_VHDL / _DDS48 / _SCALED)
+//   bhw::cordic_atan2() <->  entity cordic_atan2            src/cordic_atan2.vhd:64-76
 // Same names, argument meaning and error behaviour (unknown win_type -> zeros, like win_empty,
 // hls/windows/win_function.cpp:159-165,417-419).  All arithmetic runs in the HIP kernels behind the ABI.
 #pragma once
@@ -116,10 +118,20 @@ inline void cordic(uint32_t model, unsigned PHASE_WIDTH, unsigned DATA_WIDTH, ui
     bhw_params p;
     bhw_params_init(&p, BHW_WIN_HAMMING, PHASE_WIDTH, DATA_WIDTH);
     p.model = model;
-    check(bhw_params_validate(&p));
     s.resize(count);
     c.resize(count);
     check(bhw_sincos_to_host(&p, device, theta0, count, s.data(), c.data()));
+}
+
+// entity cordic_atan2 (src/cordic_atan2.vhd:64-76) over host vectors VEC_DX, VEC_DY -> PHI_DT.
+inline std::vector<int32_t> cordic_atan2(unsigned PRECISION, unsigned INPUT_WIDTH, unsigned ANGLE_WIDTH,
+                                         const std::vector<int32_t> &VEC_DX, const std::vector<int32_t> &VEC_DY, int device = 0)
+{
+    if (VEC_DX.size() != VEC_DY.size()) throw error(BHW_ERR_BADARG, "VEC_DX / VEC_DY lengths differ");
+    bhw_atan2_params p{(uint32_t)sizeof(bhw_atan2_params), PRECISION, INPUT_WIDTH, ANGLE_WIDTH};
+    std::vector<int32_t> phi(VEC_DX.size());
+    check(bhw_atan2_to_host(&p, device, VEC_DX.size(), VEC_DX.data(), VEC_DY.data(), phi.data()));
+    return phi;
 }
 
 } // namespace bhw

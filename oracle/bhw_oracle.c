@@ -163,12 +163,48 @@ static void cordic_vhdl(unsigned PW, unsigned W, unsigned P, uint64_t theta, int
     *oc = dc; *os = ds;
 }
 
+/* Variant generators src/cordic_dds48.vhd:94-260 (SIZE = DWPH = 48) and src/cordic_dds_scaled.vhd:98-286
+ * (SIZE = SEL_SIZE(DATA_WIDTH-8) :102-107, DWPH = max(SIZE, PHASE_WIDTH) :133-143).  Unlike models A-C the quadrant
+ * is folded into the start vector (dds48 :170-216), the x/y update has the opposite sense (:234-242), all DATA_WIDTH
+ * stages rotate (:233) and the arctangent ROM is T2 at full DWPH width (:130-138 / scaled :147-155). */
+static const unsigned k_sel_size[25] = { 15, 15, 15, 18, 21, 22, 23, 26, 30, 31, 32, 33,
+                                         38, 38, 38, 42, 42, 45, 47, 47, 47, 48, 48, 48, 48 };
+
+static void cordic_prerot(unsigned PW, unsigned W, unsigned SIZE, unsigned DWPH, uint64_t theta,
+                          int64_t *oc, int64_t *os, uint64_t *ev)
+{
+    const int64_t gain = g_g46 >> (48 - SIZE);       /* GAIN48(47 downto 48-SIZE): dds48 :113, scaled :112-113 */
+    const unsigned q = (unsigned)((theta >> (PW - 2)) & 3u);             /* dds48 :167 */
+    const uint64_t low = theta & ((1ull << (PW - 2)) - 1ull);
+    uint64_t t;                                      /* init_t: dds48 :169-186 */
+    int64_t x, y;                                    /* init_x / init_y: :191-216 */
+    switch (q) {
+    case 1:  t = low;                          x = 0;    y = wrap(-gain, SIZE, ev); break;   /* "00" & low, y = not(G)+1 */
+    case 2:  t = (3ull << (PW - 2)) | low;     x = 0;    y = gain; break;                    /* "11" & low */
+    default: t = theta;                        x = gain; y = 0; break;
+    }
+    /* init_z: phase at the MSBs of the DWPH-bit word (dds48 :163-164, scaled :180-186) */
+    int64_t z = wrap((int64_t)(t << (DWPH - PW)), DWPH, NULL);
+    for (unsigned ii = 0; ii < W; ++ii) {            /* dds48 :233-243 */
+        const int64_t xs = asr(x, ii), ys = asr(y, ii);
+        if (z >= 0) { x = wrap(x + ys, SIZE, ev); y = wrap(y - xs, SIZE, ev); }
+        else        { x = wrap(x - ys, SIZE, ev); y = wrap(y + xs, SIZE, ev); }
+        if (ii + 1 < W) {                            /* :245-251  sigZ has DATA_WIDTH entries */
+            const int64_t rom = g_t2[ii] >> (48 - DWPH);
+            z = wrap(z < 0 ? z + rom : z - rom, DWPH, ev);
+        }
+    }
+    *os = asr(y, SIZE - W);                          /* :257-258  top DATA_WIDTH bits */
+    *oc = asr(x, SIZE - W);
+}
+
 static int widths_ok(uint32_t model, uint32_t PW, uint32_t W, uint32_t P)
 {
     if (PW < 3 || PW > 32 || W < 4 || W > 32) return 0;
     if (model == BHWO_MODEL_HLS && PW > W + 2) return 0;   /* HLS init_t truncation, SURVEY section 7 */
     if (model == BHWO_MODEL_VHDL && (P < 1 || P > 7)) return 0;
-    return model <= BHWO_MODEL_VHDL;
+    if (model == BHWO_MODEL_SCALED && W < 8) return 0;      /* SEL_SIZE(DATA_WIDTH-8) */
+    return model <= BHWO_MODEL_SCALED;
 }
 
 int bhwo_cordic(uint32_t model, uint32_t PW, uint32_t W, uint32_t P, uint64_t theta,
@@ -180,9 +216,46 @@ int bhwo_cordic(uint32_t model, uint32_t PW, uint32_t W, uint32_t P, uint64_t th
     int64_t c = 0, s = 0;
     if (model == BHWO_MODEL_HLS) cordic_hls(PW, W, theta, &c, &s, wrap_events);
     else if (model == BHWO_MODEL_CPP) cordic_cpp(PW, W, theta, &c, &s);
-    else cordic_vhdl(PW, W, P, theta, &c, &s, wrap_events);
+    else if (model == BHWO_MODEL_VHDL) cordic_vhdl(PW, W, P, theta, &c, &s, wrap_events);
+    else if (model == BHWO_MODEL_DDS48) cordic_prerot(PW, W, 48, 48, theta, &c, &s, wrap_events);
+    else {
+        const unsigned size = k_sel_size[W - 8];
+        cordic_prerot(PW, W, size, size < PW ? PW : size, theta, &c, &s, wrap_events);
+    }
     if (out_cos) *out_cos = (int32_t)c;
     if (out_sin) *out_sin = (int32_t)s;
+    return 0;
+}
+
+/* Vectoring CORDIC src/cordic_atan2.vhd:82-219 (as read; no simulator, no testbench upstream).
+ * x, y are INPUT_WIDTH-bit two's-complement inputs; the result is the ANGLE_WIDTH-bit word the entity drives. */
+int bhwo_atan2(uint32_t P, uint32_t IW, uint32_t AW, int64_t vx, int64_t vy, int32_t *out_phi)
+{
+    if (P < 1 || P > 7 || AW < 4 || AW > 32 || IW < AW - 1 || IW > 32) return -1;   /* VEC_DX(ii), ii <= ANGLE_WIDTH-2 :142-145 */
+    build_tables();
+    const unsigned B = AW + P;
+    const uint64_t ux = (uint64_t)vx & ((1ull << IW) - 1ull), uy = (uint64_t)vy & ((1ull << IW) - 1ull);
+    const unsigned sx = (unsigned)(ux >> (IW - 1)) & 1u, sy = (unsigned)(uy >> (IW - 1)) & 1u;
+    const uint64_t lowm = (1ull << (AW - 1)) - 1ull;
+    int64_t x = (int64_t)((sx ? ~ux : ux) & lowm);   /* :142-147  bit-wise xor with the sign, upper bits 0 */
+    int64_t y = (int64_t)((sy ? ~uy : uy) & lowm);
+    int64_t z = 0;                                   /* :152 */
+    for (unsigned ii = 0; ii + 1 < AW; ++ii) {       /* :172-190  ANGLE_WIDTH-1 stages, steered by the sign of y */
+        const int64_t rom = g_t4[ii] >> (49 - B);    /* :100-103  top B-1 bits, MSB 0 */
+        const int64_t xs = asr(x, ii), ys = asr(y, ii);
+        if (y >= 0) { x = wrap(x + ys, B, NULL); y = wrap(y - xs, B, NULL); z = wrap(z - rom, B, NULL); }
+        else        { x = wrap(x - ys, B, NULL); y = wrap(y + xs, B, NULL); z = wrap(z + rom, B, NULL); }
+    }
+    const int64_t phi = wrap(asr(z, P), AW, NULL);   /* :194  sigZ(ANGLE_WIDTH-1)(B-1 downto PRECISION) */
+    const int64_t pi_word = (int64_t)1 << (AW - 2);  /* :112  PHI_PI */
+    int64_t out;
+    switch ((sx << 1) | sy) {                        /* :126-128, :207-213 */
+    case 0:  out = phi; break;
+    case 1:  out = wrap(phi + pi_word, AW, NULL); break;
+    case 2:  out = wrap(-phi, AW, NULL); break;
+    default: out = wrap(phi - pi_word, AW, NULL); break;
+    }
+    if (out_phi) *out_phi = (int32_t)out;
     return 0;
 }
 
@@ -349,6 +422,7 @@ static int params_ok(const bhwo_params *p)
         if (p->phi_width < 4 || p->phi_width > 32 || p->dat_width < 4 || p->dat_width > 32) return 0;
         return p->lut_size >= 1 && p->lut_size <= 20;
     }
+    if (p->model > BHWO_MODEL_VHDL) return 0;                        /* dds48 / scaled feed no window upstream */
     return widths_ok(p->model, p->phi_width, p->dat_width, p->precision);
 }
 

@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-enum { BHWO_MODEL_HLS = 0, BHWO_MODEL_CPP = 1, BHWO_MODEL_VHDL = 2 };
+enum { BHWO_MODEL_HLS = 0, BHWO_MODEL_CPP = 1, BHWO_MODEL_VHDL = 2,
+       BHWO_MODEL_DDS48 = 3,  /* src/cordic_dds48.vhd       (sin/cos only: no window instantiates it) */
+       BHWO_MODEL_SCALED = 4  /* src/cordic_dds_scaled.vhd  (sin/cos only)                            */ };
 enum { BHWO_COMBINE_HLS = 0, BHWO_COMBINE_VHDL = 1 };
 enum { BHWO_SIN_CORDIC = 0, BHWO_SIN_TAYLOR = 1, BHWO_SIN_TAYLOR_ALL = 2 /* extension: see include/bhw.h */ };
 
@@ -55,6 +57,10 @@ int64_t bhwo_gain47(void);            /* round(2^47 / K) */
  * NULL) is incremented whenever a typed store actually changed a value. */
 int bhwo_cordic(uint32_t model, uint32_t phi_width, uint32_t dat_width, uint32_t precision,
                 uint64_t theta, int32_t *out_cos, int32_t *out_sin, uint64_t *wrap_events);
+
+/* Vectoring CORDIC src/cordic_atan2.vhd: x, y are INPUT_WIDTH-bit two's-complement words, *out_phi the ANGLE_WIDTH-bit
+ * word PHI_DT (sign-extended).  PARITY UNPINNED like every VHDL-only item. */
+int bhwo_atan2(uint32_t precision, uint32_t input_width, uint32_t angle_width, int64_t x, int64_t y, int32_t *out_phi);
 
 /* Taylor feeder (src/taylor_sincos.vhd + src/tay1_order.vhd). */
 int bhwo_taylor(uint32_t phi_width, uint32_t dat_width, uint32_t lut_size,

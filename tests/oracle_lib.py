@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
 REF_DIR = os.path.join(ROOT, "oracle", "_ref")
 
-MODEL_HLS, MODEL_CPP, MODEL_VHDL = 0, 1, 2
+MODEL_HLS, MODEL_CPP, MODEL_VHDL, MODEL_DDS48, MODEL_SCALED = 0, 1, 2, 3, 4
 COMBINE_HLS, COMBINE_VHDL = 0, 1
 SIN_CORDIC, SIN_TAYLOR, SIN_TAYLOR_ALL = 0, 1, 2
 TERMS = {1: 2, 2: 2, 3: 3, 4: 4, 5: 5, 7: 7}
@@ -91,6 +91,19 @@ def sincos(p, theta0, count):
     if rc:
         raise ValueError("oracle rejected the parameters")
     return s, c
+
+
+def atan2(precision, input_width, angle_width, x, y):
+    """cordic_atan2 restatement over integer arrays x, y."""
+    o = oracle()
+    o.bhwo_atan2.argtypes = [ctypes.c_uint32] * 3 + [ctypes.c_int64] * 2 + [ctypes.c_void_p]
+    one = np.empty(1, np.int32)
+    out = np.empty(len(x), np.int32)
+    for i, (a, b) in enumerate(zip(x, y)):
+        if o.bhwo_atan2(precision, input_width, angle_width, int(a), int(b), one.ctypes.data):
+            raise ValueError("oracle rejected the atan2 parameters")
+        out[i] = one[0]
+    return out
 
 
 def taylor(phi_width, dat_width, lut_size, phases):

@@ -117,6 +117,49 @@ def test_win_selector_ignores_taylor_for_4_5_7_terms_like_the_reference(torch):
     assert np.abs(c - ideal).max() < 12
 
 
+@pytest.mark.parametrize("model", [B.MODEL_DDS48, B.MODEL_SCALED])
+@pytest.mark.parametrize("pw,w", [(10, 16), (12, 12), (14, 24), (16, 32), (20, 8), (26, 32), (30, 20), (13, 31), (9, 29)])
+def test_variant_generators_match_oracle(torch, model, pw, w):
+    """cordic_dds48 / cordic_dds_scaled through bhw_sincos_device vs the restatement of the two entities."""
+    import blackman_harris_win_amd as bhw
+    p = B.make_params(1, pw, w, model=model)
+    n = 1 << pw
+    for t0, cnt in ((0, min(n, 3000)), (n // 4 - 700, 1400), (n // 2 - 5, 1500), (3 * (n // 4) - 33, 900), (n - 1000, 2100)):
+        t0 = max(t0, 0)
+        s, c = bhw.cordic(p, t0, cnt)
+        ws, wc = O.sincos(O.from_bhw(p), t0, cnt)
+        assert np.array_equal(s.cpu().numpy(), ws) and np.array_equal(c.cpu().numpy(), wc), (t0, cnt)
+    with pytest.raises(B.BhwError):                                    # sin/cos sources only
+        gpu_generate(p, 0, 16)
+
+
+@pytest.mark.parametrize("P,IW,AW", [(1, 23, 24), (3, 16, 16), (4, 32, 32), (2, 15, 16), (7, 25, 12), (1, 3, 4), (5, 31, 32)])
+def test_atan2_matches_oracle(torch, P, IW, AW):
+    import blackman_harris_win_amd as bhw
+    rng = np.random.default_rng(P * 1000 + AW)
+    lo, hi = -(1 << (IW - 1)), (1 << (IW - 1)) - 1
+    x = rng.integers(lo, hi + 1, 6000)
+    y = rng.integers(lo, hi + 1, 6000)
+    edge = np.array([0, 1, -1, lo, hi, lo + 1, hi - 1, 1 << max(AW - 2, 0), -(1 << max(AW - 2, 0))], dtype=np.int64)
+    edge = edge[(edge >= lo) & (edge <= hi)]
+    x = np.concatenate([x, np.repeat(edge, len(edge))])
+    y = np.concatenate([y, np.tile(edge, len(edge))])
+    tx = torch.tensor(x.astype(np.int32), device="cuda")
+    ty = torch.tensor(y.astype(np.int32), device="cuda")
+    got = bhw.atan2(tx, ty, PRECISION=P, INPUT_WIDTH=IW, ANGLE_WIDTH=AW).cpu().numpy()
+    assert np.array_equal(got, O.atan2(P, IW, AW, x, y))
+
+
+def test_atan2_rejects_unbuildable_generics(torch):
+    import blackman_harris_win_amd as bhw
+    z = torch.zeros(4, dtype=torch.int32, device="cuda")
+    with pytest.raises(B.BhwError) as e:
+        bhw.atan2(z, z, PRECISION=1, INPUT_WIDTH=20, ANGLE_WIDTH=24)     # upstream defaults: VEC_DX(22) does not exist
+    assert e.value.code == -2
+    with pytest.raises(B.BhwError):
+        bhw.atan2(z, z, PRECISION=0, INPUT_WIDTH=20, ANGLE_WIDTH=16)
+
+
 def test_golden_reference_sincos(torch, golden, golden_dir):
     """GPU cordic() vs vectors produced by the reference's own compiled cordic() (model CPP)."""
     import blackman_harris_win_amd as bhw

@@ -206,6 +206,55 @@ def test_taylor_all_extension():
         assert np.abs(c4.astype(np.int64) - c1).max() <= 8      # same angle, different rounding path
 
 
+# ---- variant generators: restated from source, no upstream vectors -> sanity against the ideal functions
+@pytest.mark.parametrize("model", [O.MODEL_DDS48, O.MODEL_SCALED])
+def test_variant_generators_close_to_float(model):
+    """cordic_dds48 / cordic_dds_scaled as written: DT_COS = +cos, DT_SIN = -sin at amplitude 2^(DATA_WIDTH-2)."""
+    for pw, w in [(10, 16), (12, 12), (14, 24), (13, 32), (16, 8), (9, 20)]:
+        n = 1 << pw
+        th = np.arange(n) if pw <= 12 else np.random.default_rng(pw).integers(0, n, 3000)
+        p = O.oparams(1, pw, w, model=model)
+        s = np.empty(len(th), np.int32)
+        c = np.empty(len(th), np.int32)
+        for i, t in enumerate(th):
+            s1, c1 = O.sincos(p, int(t), 1)
+            s[i], c[i] = s1[0], c1[0]
+        x = 2 * math.pi * th / n
+        amp = 2.0 ** (w - 2)
+        assert np.abs(c - amp * np.cos(x)).max() < 3 and np.abs(s + amp * np.sin(x)).max() < 3
+    with pytest.raises(ValueError):                                   # no window entity instantiates them
+        O.generate(O.oparams(4, 10, 16, model=model), 0, 4)
+
+
+def test_dds48_is_the_48_bit_case_of_scaled():
+    """SEL_SIZE(DATA_WIDTH-8) = 48 from DATA_WIDTH = 29 on (src/cordic_dds_scaled.vhd:102-107): both entities agree there."""
+    for w in (29, 30, 32):
+        a = O.sincos(O.oparams(1, 12, w, model=O.MODEL_DDS48), 0, 4096)
+        b = O.sincos(O.oparams(1, 12, w, model=O.MODEL_SCALED), 0, 4096)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    a = O.sincos(O.oparams(1, 12, 16, model=O.MODEL_DDS48), 0, 4096)
+    b = O.sincos(O.oparams(1, 12, 16, model=O.MODEL_SCALED), 0, 4096)
+    assert not (np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]))   # 30-bit data path rounds differently
+
+
+def test_atan2_as_written():
+    """cordic_atan2 as written (src/cordic_atan2.vhd:207-213): z accumulates -atan(|y|/|x|), PHI_PI is a quarter turn."""
+    rng = np.random.default_rng(5)
+    for P, IW, AW in [(1, 23, 24), (3, 16, 16), (4, 32, 32), (2, 15, 16)]:
+        lim = 1 << (min(IW, AW - 1) - 1)
+        x = rng.integers(lim // 4, lim, 600) * rng.choice([-1, 1], 600)      # well-conditioned magnitudes
+        y = rng.integers(lim // 4, lim, 600) * rng.choice([-1, 1], 600)
+        got = O.atan2(P, IW, AW, x, y).astype(np.float64)
+        phi0 = np.arctan2(np.abs(y), np.abs(x)) / (2 * math.pi) * 2.0 ** AW
+        quarter = 2.0 ** AW / 4
+        want = np.where((x >= 0) & (y >= 0), -phi0, np.where((x >= 0) & (y < 0), -phi0 + quarter,
+                        np.where((x < 0) & (y >= 0), phi0, -phi0 - quarter)))
+        d = (got - want + 2.0 ** (AW - 1)) % 2.0 ** AW - 2.0 ** (AW - 1)
+        assert np.abs(d).max() < 2.0 ** AW * 4 / lim + 8, (P, IW, AW, np.abs(d).max())
+    with pytest.raises(ValueError):
+        O.atan2(1, 20, 24, [1], [1])        # upstream default generics: VEC_DX(22) does not exist
+
+
 # ---- structural facts the kernels rely on -----------------------------------------------------------
 def test_typed_store_wraps_never_fire():
     """The W+2 / W+P bit wraps of the HLS/VHDL CORDIC never change a value (kernels omit them)."""

@@ -1,6 +1,7 @@
 """In-process A/B of compile-time variants of libbhw.so (GPU box): every variant is built to its own .so, all are
 loaded side by side and timed interleaved on the same device and clocks, which removes the box-to-box and
 clock-ramp noise of separate bench runs.  usage: python tools/ab_inproc.py "<flags A>" "<flags B>" ...
+env: AB_WIN (7) AB_PW (26) AB_W (32) AB_SIN (0) AB_COMBINE (0) AB_MODEL (0) AB_L (9) AB_ROUNDS (8) AB_INNER (100)
 """
 import ctypes
 import os
@@ -50,6 +51,10 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     p = binding.BhwParams()
     libs[0].bhw_params_init(ctypes.byref(p), win, pw, width)
+    p.sin_type = int(os.environ.get("AB_SIN", "0"))
+    p.combine = int(os.environ.get("AB_COMBINE", "0"))
+    p.model = int(os.environ.get("AB_MODEL", "0"))
+    p.lut_size = int(os.environ.get("AB_L", "9"))
     ref = None
     for L in libs:
         rc = L.bhw_generate_device(ctypes.byref(p), 0, ctypes.c_void_p(st), 0, n, ctypes.c_void_p(out.data_ptr()))
