@@ -189,6 +189,33 @@ def main():
     oracle_only("cpp_bh7_12_32_hlscombine", O.oparams(7, 12, 32, model=O.MODEL_CPP), 0, 4096,
                 note="model A cosines (pinned by oracle/_ref) in the HLS cosine-sum rule")
 
+    # ---- the all-term-count Taylor extension and the variant generators (all oracle-only) ----
+    ext = "extension BHW_SIN_TAYLOR_ALL (include/bhw.h): no reference counterpart, the oracle defines it"
+    oracle_only("taylor_all_bh7_12_24_l9", O.oparams(7, 12, 24, combine=O.COMBINE_VHDL, sin_type=O.SIN_TAYLOR_ALL, lut_size=9),
+                0, 4096, keep=False, note=ext)
+    oracle_only("taylor_all_bh5_13_16_l9", O.oparams(5, 13, 16, sin_type=O.SIN_TAYLOR_ALL, lut_size=9), 0, 8192, keep=False, note=ext)
+    oracle_only("taylor_all_bh4_14_32_l10", O.oparams(4, 14, 32, combine=O.COMBINE_VHDL, sin_type=O.SIN_TAYLOR_ALL, lut_size=10),
+                100, 16384, keep=False, note=ext)
+    for name, model, pw, w in (("sincos_dds48_12_16", O.MODEL_DDS48, 12, 16), ("sincos_dds48_14_32", O.MODEL_DDS48, 14, 32),
+                               ("sincos_scaled_12_16", O.MODEL_SCALED, 12, 16), ("sincos_scaled_14_24", O.MODEL_SCALED, 14, 24),
+                               ("sincos_scaled_20_10", O.MODEL_SCALED, 20, 10)):
+        po = O.oparams(1, pw, w, model=model)
+        cnt = min(1 << pw, 16384)
+        sn, cs = O.sincos(po, (1 << pw) - cnt // 2 if pw > 14 else 0, cnt)
+        E[name] = {"source": "oracle", "note": "parity unpinned: restated from src/cordic_dds48.vhd / src/cordic_dds_scaled.vhd",
+                   "params": pdict(po), "theta0": (1 << pw) - cnt // 2 if pw > 14 else 0, "count": cnt,
+                   "sin_md5": md5(sn), "cos_md5": md5(cs)}
+    rng2 = np.random.default_rng(20241003)
+    for P, IW, AW in ((1, 23, 24), (3, 16, 16), (4, 32, 32)):
+        lo, hi = -(1 << (IW - 1)), (1 << (IW - 1)) - 1
+        x = rng2.integers(lo, hi + 1, 1500)
+        y = rng2.integers(lo, hi + 1, 1500)
+        phi = O.atan2(P, IW, AW, x, y)
+        name = f"atan2_p{P}_{IW}_{AW}"
+        np.save(os.path.join(HERE, name + ".npy"), np.stack([x.astype(np.int64), y.astype(np.int64), phi.astype(np.int64)]))
+        E[name] = {"source": "oracle", "note": "parity unpinned: restated from src/cordic_atan2.vhd; rows: VEC_DX, VEC_DY, PHI_DT",
+                   "file": name + ".npy", "precision": P, "input_width": IW, "angle_width": AW}
+
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("wrote", len(E), "entries")

@@ -53,11 +53,33 @@ def test_golden_windows(torch, golden, golden_dir, name, algo):
     assert O.fnv(got) == e["fnv1a64"]
 
 
-@pytest.mark.parametrize("name", ["taylor_hamming_12_16_l9", "taylor_bh3_14_24_l9"])
+@pytest.mark.parametrize("name", ["taylor_hamming_12_16_l9", "taylor_bh3_14_24_l9", "taylor_all_bh7_12_24_l9",
+                                  "taylor_all_bh5_13_16_l9", "taylor_all_bh4_14_32_l10"])
 def test_golden_taylor(torch, golden, golden_dir, name):
     e = golden[name]
     got = gpu_generate(params_from_golden(e["params"]), e["n0"], e["count"])
     assert _md5(got) == e["md5"]
+
+
+def test_golden_variant_generators(torch, golden, golden_dir):
+    """Committed vectors of cordic_dds48 / cordic_dds_scaled / cordic_atan2 (oracle-made: parity unpinned)."""
+    import blackman_harris_win_amd as bhw
+    names = [k for k in golden if k.startswith("sincos_dds48_") or k.startswith("sincos_scaled_")]
+    assert len(names) >= 5
+    for name in names:
+        e = golden[name]
+        pr = e["params"]
+        p = B.make_params(1, pr["phi_width"], pr["dat_width"], model=pr["model"])
+        s, c = bhw.cordic(p, e["theta0"], e["count"])
+        assert _md5(s.cpu().numpy()) == e["sin_md5"] and _md5(c.cpu().numpy()) == e["cos_md5"], name
+    names = [k for k in golden if k.startswith("atan2_")]
+    assert len(names) >= 3
+    for name in names:
+        e = golden[name]
+        x, y, phi = np.load(os.path.join(golden_dir, e["file"]))
+        got = bhw.atan2(torch.tensor(x.astype(np.int32), device="cuda"), torch.tensor(y.astype(np.int32), device="cuda"),
+                        PRECISION=e["precision"], INPUT_WIDTH=e["input_width"], ANGLE_WIDTH=e["angle_width"])
+        assert np.array_equal(got.cpu().numpy(), phi.astype(np.int32)), name
 
 
 # Taylor source: reference wiring (2-/3-term) and the all-term-count extension (BHW_SIN_TAYLOR_ALL, include/bhw.h).
