@@ -335,15 +335,14 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
     const bool has_period = count >= (N - n0 % N) % N + N;
     const bool tiled = has_period && bhwk_tile_applicable(c, w);
     c.tab_split = (tiled && c.z_shr == 0) ? 1u : 0u;
-    // large whole-period tables are stored residual-compressed (2 bytes per entry + one exact record per 2^d entries);
-    // both live inside the same scratch: [ residual table, E * 2 B | ... | coarse records at byte offset E * 4 ]
-    // (measured on MI355X: 4x less table traffic but +9 % time -- the combine pass is bound by L1 line accesses of its
-    // strided gathers, not by bytes -- so it is off unless BHW_TABLE_COMPRESS=1 is set in the environment)
-    static const bool compress = [] { const char *e = getenv("BHW_TABLE_COMPRESS"); return e && e[0] == '1'; }();
-    c.tab_dlog = (tiled && compress) ? bhwk_comp_dlog(c) : 0u;
+    // whole-period tile tables are stored packed when the widths allow it (4 bytes per entry + one int2 record per 64
+    // entries instead of 8 bytes per entry): the combine pass is bound by table + output traffic, and this halves the
+    // table's share.  Both parts live in the same scratch: [ deltas, E * 4 B | block heads at byte offset E * 4, E / 8 B ].
+    // BHW_TABLE_PACK=0 in the environment keeps the plain int2 table (A/B and equivalence tests).
+    static const bool pack = [] { const char *e = getenv("BHW_TABLE_PACK"); return !(e && e[0] == '0'); }();
+    c.tab_dlog = (tiled && pack && bhwk_packed_ok(c)) ? 6u : 0u;
     c.tab_coarse = c.tab_dlog ? (const void *)((const char *)ws + table_entries(c) * 4ull) : nullptr;
-    int e = bhwk_coarse_build(l, c);
-    if (e) return fail_hip(e, "coarse table launch");
+    int e;
     e = bhwk_table_build(l, c, (int32_t *)ws);
     if (e) return fail_hip(e, "table build launch");
     if (ex && ex->event_after_build) {

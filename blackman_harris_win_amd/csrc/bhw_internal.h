@@ -21,7 +21,8 @@ struct BhwCordicCfg {
     uint32_t ones_neg;    // 1: quadrant map negates with ~v (CPP); 0: -v
     uint32_t wide;        // 1: state needs more than 32 bits
     uint32_t tab_split;   // table layout: 0 natural index u; 1 split by residue class (u%4==0 | u%4==2 | u odd)
-    uint32_t tab_dlog;    // 0: entries are int2 (c, s); d > 0: entries are 2-byte residuals against the coarse table
+    uint32_t tab_dlog;    // 0: entries are int2 (c, s); 6: packed -- one dword of two int16 differences to the first entry of the
+                          // 64-entry block, block heads as int2 records at tab_coarse
                           //    (one exact (c, s, dc, ds) record per 2^d entries + linear prediction), see tab_load()
     const void *tab_coarse;
 };
@@ -76,8 +77,7 @@ int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table
 int bhwk_table_combine(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table,
                        uint64_t n0, uint64_t count, int32_t *d_out);
 // coarse records for the residual-compressed table (cfg.tab_dlog > 0): int4 {c, s, dc, ds} per 2^tab_dlog entries
-int bhwk_coarse_build(const BhwLaunch &l, const BhwCordicCfg &c);
-uint32_t bhwk_comp_dlog(const BhwCordicCfg &c);
+bool bhwk_packed_ok(const BhwCordicCfg &c);
 // whole period [0, 2^PW) via the quadrant fold (one lane per four coefficients)
 int bhwk_table_combine_fold(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out);
 // whole period, 15-block super-tiles over the residue-split table (z_shr == 0 only)

@@ -86,41 +86,35 @@ __device__ __forceinline__ uint32_t tab_index(uint32_t u, uint32_t log2_entries,
     return (u >> (2u - odd)) + (odd ? (e >> 1) : mid);
 }
 
-// Residual-compressed table (cfg.tab_dlog = d > 0, z_shr == 0 only).  (c, s)(t) is smooth in t: between two exact
-// records 2^d entries apart it deviates from the straight line through them by the CORDIC's own rounding noise
-// (a few LSB) plus < 1 LSB of curvature (d is chosen for that, bhwk_comp_dlog).  The table stores that deviation in
-// one byte per component -- 2 bytes per entry instead of 8 -- and both passes evaluate the same integer predictor
-//   pred(t) = rec.c + ((rec.dc * (t mod 2^d)) >> d)          rec = coarse[t >> d] = {c, s, dc, ds}
-// so the reconstruction is exact.  |deviation| <= ~30 for every width (<= 32 rotations of < 1 LSB each, twice), far
-// inside int8.
-__device__ __forceinline__ int2 tab_predict(const int4 rec, uint32_t f, uint32_t d)
-{
-    return make_int2(rec.x + ((rec.z * (int32_t)f) >> d), rec.y + ((rec.w * (int32_t)f) >> d));
-}
+// Packed table (cfg.tab_dlog = 6, z_shr == 0 only).  (c, s)(t) is smooth in t: inside an aligned block of 64 entries it
+// moves by at most 63 * 2 pi * 2^(W-2-PW) (+ the CORDIC's rounding noise of a few LSB), which fits int16 whenever
+// W - PW <= 8 (bhwk_packed_ok).  The table then stores, per entry, the two 16-bit differences to the block's first entry
+// in one dword, and the first entries themselves as int2 records in a side array (8 bytes per 64 entries, E/8 bytes in all:
+// L2-resident).  Exact by construction -- no predictor, two adds to unpack -- and the window's table traffic, which
+// bounds the combine pass, halves.
+constexpr uint32_t kPackLog = 6;
 
 template <int KCLASS = 0, bool COMP = true>
 __device__ __forceinline__ int2 tab_load(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t log2_entries)
 {
     const uint32_t idx = tab_index<KCLASS>(u, log2_entries, cfg.tab_split);
-    const uint32_t d = COMP ? cfg.tab_dlog : 0u;
-    if (d == 0) return reinterpret_cast<const int2 *>(table)[idx];
-    const uint32_t r = reinterpret_cast<const uint16_t *>(table)[idx];
-    const int4 rec = reinterpret_cast<const int4 *>(cfg.tab_coarse)[u >> d];
-    const int2 p = tab_predict(rec, u & ((1u << d) - 1u), d);
-    return make_int2(p.x + (int32_t)(int8_t)(r & 0xFFu), p.y + (int32_t)(int8_t)(r >> 8));
+    if (!COMP || cfg.tab_dlog == 0) return reinterpret_cast<const int2 *>(table)[idx];
+    const uint32_t e = reinterpret_cast<const uint32_t *>(table)[idx];
+    const int2 base = reinterpret_cast<const int2 *>(cfg.tab_coarse)[u >> kPackLog];
+    return make_int2(base.x + (int32_t)(int16_t)(e & 0xFFFFu), base.y + ((int32_t)e >> 16));
 }
 
-__device__ __forceinline__ void tab_store(void *__restrict__ table, uint32_t u, uint32_t log2_entries, uint32_t split, uint32_t d,
-                                          const void *coarse, int32_t c, int32_t s)
+// `base` = (c, s) of the first entry of u's 64-entry block (packed format only; the caller holds it: lane 0 of the wave)
+__device__ __forceinline__ void tab_store(void *__restrict__ table, uint32_t u, uint32_t log2_entries, uint32_t split, uint32_t packed,
+                                          void *coarse, int32_t c, int32_t s, int2 base)
 {
     const uint32_t idx = tab_index(u, log2_entries, split);
-    if (d == 0) {
+    if (!packed) {
         reinterpret_cast<int2 *>(table)[idx] = make_int2(c, s);
         return;
     }
-    const int4 rec = reinterpret_cast<const int4 *>(coarse)[u >> d];
-    const int2 p = tab_predict(rec, u & ((1u << d) - 1u), d);
-    reinterpret_cast<uint16_t *>(table)[idx] = (uint16_t)(((uint32_t)(c - p.x) & 0xFFu) | (((uint32_t)(s - p.y) & 0xFFu) << 8));
+    reinterpret_cast<uint32_t *>(table)[idx] = ((uint32_t)(c - base.x) & 0xFFFFu) | ((uint32_t)(s - base.y) << 16);
+    if ((u & ((1u << kPackLog) - 1u)) == 0u) reinterpret_cast<int2 *>(coarse)[u >> kPackLog] = make_int2(c, s);
 }
 
 // Accumulate one harmonic.  HLS rule: hls/windows/win_function.cpp:368-375;
@@ -221,8 +215,10 @@ __global__ __launch_bounds__(kBlock) void k_table_build(BhwCordicCfg cfg, uint32
     if (u >= entries) return;
     T x, y;
     cordic_q1<T>(lut_s, (T)cfg.x0, (T)((T)u << cfg.z_shl), (int)cfg.n_iter, x, y);
-    tab_store(table, u, cfg.phi_width - 2 - cfg.z_shr, cfg.tab_split, cfg.tab_dlog, cfg.tab_coarse,
-              (int32_t)(x >> cfg.out_shr), (int32_t)(y >> cfg.out_shr));
+    const int32_t c = (int32_t)(x >> cfg.out_shr), sn = (int32_t)(y >> cfg.out_shr);
+    // a wave holds one aligned 64-entry block (the packed format needs entries >= 64, see bhwk_packed_ok)
+    const int2 base = make_int2(__builtin_amdgcn_readfirstlane(c), __builtin_amdgcn_readfirstlane(sn));
+    tab_store(table, u, cfg.phi_width - 2 - cfg.z_shr, cfg.tab_split, cfg.tab_dlog, const_cast<void *>(cfg.tab_coarse), c, sn, base);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -253,7 +249,7 @@ struct BhwBuildPlan {
     uint32_t out_shr;
     uint32_t log2_entries;
     uint32_t tab_split;
-    uint32_t tab_dlog;        // residual compression (see tab_load)
+    uint32_t tab_dlog;        // packed table format (see tab_load)
     uint32_t pad0;
     const void *tab_coarse;
     uint32_t groups_per_wg;   // 4, 16 or 64: small tables use small workgroups so the grid still fills the chip
@@ -338,36 +334,10 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
         for (int k = 1; k < NITER; ++k) {
             if (k >= k0) rot_step(x, y, z, k, plan.lut[k]);
         }
-        tab_store(table, (g << 6) + lane, plan.log2_entries, plan.tab_split, plan.tab_dlog, plan.tab_coarse,
-                  (int32_t)(x >> plan.out_shr), (int32_t)(y >> plan.out_shr));
+        const int32_t c = (int32_t)(x >> plan.out_shr), sn = (int32_t)(y >> plan.out_shr);
+        const int2 base = make_int2(__builtin_amdgcn_readfirstlane(c), __builtin_amdgcn_readfirstlane(sn));   // leaf 0 of the group
+        tab_store(table, (g << 6) + lane, plan.log2_entries, plan.tab_split, plan.tab_dlog, const_cast<void *>(plan.tab_coarse), c, sn, base);
     }
-}
-
-// Coarse records of the residual-compressed table: thread i evaluates the full chain (no sharing; E >> d of them) at
-// t = i*2^d and at the next grid point, and stores {c, s, dc, ds}.  The last cell has no next point inside the
-// quadrant and reuses the slope of the cell before it (its curvature error stays far inside the residual byte).
-template <int NITER>
-__global__ __launch_bounds__(kBlock) void k_coarse_build(BhwBuildPlan plan, int4 *__restrict__ coarse)
-{
-    const uint32_t d = plan.tab_dlog;
-    const uint32_t cells = plan.entries >> d;
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= cells) return;
-    const bool last = (i + 1 == cells);
-    const uint32_t ua = (last ? i - 1 : i) << d, ub = ua + (1u << d);
-    int32_t cc[2], ss[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const uint32_t u = e ? ub : ua;
-        int64_t x = plan.x0, y = plan.x0;
-        int32_t z = (int32_t)((u << plan.z_shl) - plan.lut[0]);
-#pragma unroll
-        for (int r = 1; r < NITER; ++r) rot_step(x, y, z, r, plan.lut[r]);
-        cc[e] = (int32_t)(x >> plan.out_shr);
-        ss[e] = (int32_t)(y >> plan.out_shr);
-    }
-    const int32_t dc = cc[1] - cc[0], ds = ss[1] - ss[0];
-    coarse[i] = last ? make_int4(cc[1], ss[1], dc, ds) : make_int4(cc[0], ss[0], dc, ds);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1016,56 +986,12 @@ int bhwk_replicate(const BhwLaunch &l, const int32_t *d_frame, uint64_t frame_le
     return finish(hipSuccess);
 }
 
-// Largest d <= 9 for which the straight line between records 2^d entries apart stays within half an LSB of the true
-// curve: (2 pi 2^d / 2^PW)^2 / 8 * 2^(W-2) <= 0.5.  0 = compression not applicable.
-uint32_t bhwk_comp_dlog(const BhwCordicCfg &c)
+// Packed (delta16) table format applies when the (c, s) drift across a 64-entry block fits int16 with margin:
+// 63 * 2 pi * 2^(W-2-PW) + noise < 2^15  <=>  W - PW <= 8  (25.4 k at W - PW = 8).  Amplitude is 2^(W-2) for every model.
+bool bhwk_packed_ok(const BhwCordicCfg &c)
 {
-    if (c.z_shr != 0 || c.phi_width < 20 || c.dat_width + c.out_shr > 34) return 0;
-    const int amp_bits = (int)c.dat_width - 2;                       // |c|, |s| <= 2^(W-2) (+1)
-    const int twice_d = 2 * (int)c.phi_width - amp_bits - 4;         // 4.93 * 2^(2d - 2PW + W - 2) <= 0.5
-    int d = twice_d / 2;
-    if (d > 9) d = 9;
-    if (d < 6) return 0;                                             // a 64-leaf build group must sit inside one cell
-    if ((int)c.phi_width - 2 - d < 2) return 0;
-    return (uint32_t)d;
-}
-
-static void fill_build_plan(const BhwCordicCfg &c, BhwBuildPlan &plan)
-{
-    for (uint32_t k = 0; k < 32; ++k) plan.lut[k] = (uint32_t)c.lut[k];
-    plan.entries = 1u << (c.phi_width - 2 - c.z_shr);
-    plan.n_iter = c.n_iter;
-    plan.z_shl = c.z_shl;
-    plan.out_shr = c.out_shr;
-    plan.log2_entries = c.phi_width - 2 - c.z_shr;
-    plan.tab_split = c.tab_split;
-    plan.tab_dlog = c.tab_dlog;
-    plan.pad0 = 0;
-    plan.tab_coarse = c.tab_coarse;
-    plan.groups_per_wg = 64;
-    plan.pad = 0;
-    plan.x0 = c.x0;
-}
-
-int bhwk_coarse_build(const BhwLaunch &l, const BhwCordicCfg &c)
-{
-    if (!c.tab_dlog) return 0;
-    BHW_SET_DEVICE(l);
-    hipStream_t st = (hipStream_t)l.stream;
-    BhwBuildPlan plan;
-    fill_build_plan(c, plan);
-    const uint32_t cells = plan.entries >> c.tab_dlog;
-    const dim3 grid(grid_for(cells)), block(kBlock);
-    switch (c.n_iter) {
-#define BHW_CASE(N) case N: hipLaunchKernelGGL(k_coarse_build<N>, grid, block, 0, st, plan, (int4 *)const_cast<void *>(c.tab_coarse)); break;
-        BHW_CASE(7) BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14)
-        BHW_CASE(15) BHW_CASE(16) BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20) BHW_CASE(21) BHW_CASE(22)
-        BHW_CASE(23) BHW_CASE(24) BHW_CASE(25) BHW_CASE(26) BHW_CASE(27) BHW_CASE(28) BHW_CASE(29) BHW_CASE(30)
-        BHW_CASE(31) BHW_CASE(32)
-#undef BHW_CASE
-    default: return (int)hipErrorInvalidValue;
-    }
-    return finish(hipSuccess);
+    if (c.z_shr != 0 || c.phi_width < 8) return false;
+    return (int)c.dat_width - (int)c.phi_width <= 8;
 }
 
 int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table)
