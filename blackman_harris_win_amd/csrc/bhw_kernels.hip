@@ -1087,7 +1087,10 @@ int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const Bhw
     for (int i5 = 0; i5 < nb5; ++i5)
         for (int i3 = 0; i3 < nb3; ++i3) {
             const uint32_t o = (uint32_t)(((uint64_t)i3 * inv3 + (uint64_t)i5 * inv5) & (E - 1u));
-            tp.offs[i5 + nb5 * i3] = o;      // thread group p holds the five inv5-siblings of i3 = p: k = 5 is dense per thread
+            // 3 thread groups: group p holds the five inv5-siblings of i3 = p (k = 5 dense per thread);
+            // 5 thread groups (BHW_TILE_THREADS = 5 * BHW_TILE_LANES): group p holds the three inv3-siblings of i5 = p
+            if (kTileThreads / kTileLanes == 5 && nb == 15) tp.offs[i3 + nb3 * i5] = o;
+            else tp.offs[i5 + nb5 * i3] = o;
             sorted[i3 + nb3 * i5] = o;
         }
     for (int i = nb; i < 16; ++i) tp.offs[i] = tp.offs[nb - 1];
