@@ -763,6 +763,57 @@ __device__ __forceinline__ int32_t narrow_final(int32_t acc, uint32_t W, uint32_
     return wrap32(acc, W);
 }
 
+// ---- 32-bit forms for dat_width >= 19 (the wide rounding variant, tay1_order.vhd:585-616) with 24 <= 19+L <= 32 ----
+// m < 2^24 and the ROM entries are in [0, 2^(W-1)), so (m*v) >> X is one v_mul_hi_u32 of (m << (32-X)) and v, already
+// inside W bits; C - dc cannot leave the W-bit range, S + ds can (and then saturates, as does a negative c).
+__device__ __forceinline__ void taylor_q1_w32(const BhwTaylorCfg &t, const int2 *rom, uint32_t cnt, int32_t &s, int32_t &c)
+{
+    const uint32_t pw = t.phi_width, W = t.dat_width, L = t.lut_size;
+    const uint32_t addr = (cnt >> (pw - L - 2)) & ((1u << L) - 1u);             // taylor_sincos.vhd:190-191 (mode 2 only)
+    const uint32_t f = cnt & ((1u << (pw - L - 2)) - 1u);
+    const int2 sc = rom[addr];
+    const uint32_t m = (t.pi_word * f) & 0xFFFFFFu;                             // tay1_order.vhd:133-146
+    const uint32_t ms = m << (32u - t.xshift);
+    const int32_t dc = (int32_t)__umulhi(ms, (uint32_t)sc.x);
+    const int32_t ds = (int32_t)__umulhi(ms, (uint32_t)sc.y);
+    const int32_t sat = (int32_t)((1u << (W - 1)) - 1u);
+    c = sc.y - dc;                                                              // :595-596, in range without a wrap
+    s = wrap32((int32_t)((uint32_t)sc.x + (uint32_t)ds), W);
+    if (c < 0) c = sat;                                                         // :602-616
+    if (s < 0) s = sat;
+}
+
+// W-bit sums of the cosine-sum rules in 32-bit registers.  HLS rule: everything modulo 2^32, wrapped to W bits at the end.
+// VHDL rule: the sum needs W+2 bits, so it is carried as S = 4*hi + lo (hi modulo 2^32, lo a small exact integer):
+//   b_k = wrap_W((P >> (W-1)) + ((P >> (W-2)) & 1))   == the slice-and-round of bh_win_7term.vhd:353-402 on the 2W-bit product P
+//   S>>2 = hi + (lo>>2),  (S>>1)&1 = (lo>>1)&1,  S>>1 = 2*hi + (lo>>1),  S&1 = lo&1
+struct Sum32 {
+    int32_t hi, lo;
+    __device__ __forceinline__ Sum32 &operator+=(const Sum32 &o) { hi += o.hi; lo += o.lo; return *this; }
+};
+
+template <uint32_t COMBINE>
+__device__ __forceinline__ void w32_term(Sum32 &acc, int32_t a, int32_t v, uint32_t k, uint32_t W)
+{
+    const int64_t P = (int64_t)a * (int64_t)v;
+    if constexpr (COMBINE == BHW_COMBINE_HLS) {
+        const int32_t m = (int32_t)(P >> (W - 2));
+        acc.hi += (k & 1u) ? -m : m;
+    } else {
+        const int32_t b = wrap32((int32_t)(P >> (W - 1)) + (int32_t)(((uint32_t)P >> (W - 2)) & 1u), W);
+        if (k & 1u) { acc.hi -= b >> 2; acc.lo -= b & 3; }
+        else        { acc.hi += b >> 2; acc.lo += b & 3; }
+    }
+}
+
+template <uint32_t COMBINE>
+__device__ __forceinline__ int32_t w32_final(const Sum32 &acc, uint32_t W, uint32_t n_terms)
+{
+    if constexpr (COMBINE == BHW_COMBINE_HLS) return wrap32(acc.hi, W);
+    else if (n_terms == 2) return wrap32(2 * acc.hi + (acc.lo >> 1) + (acc.lo & 1), W);          // hamming_win.vhd:214-228
+    else return wrap32(acc.hi + (acc.lo >> 2) + ((acc.lo >> 1) & 1), W);                         // bh_win_7term.vhd:409-435
+}
+
 // Whole-period Taylor window, quadrant fold: lane r in [0, N/4) owns n = r + j*N/4.  The first generator's quadrant
 // is then simply j; the 3-term window's second generator (PHASE_WIDTH-1, bh_win_3term.vhd:221-226) sees phase
 // n mod N/2 = r + (j & 1) * N/4, i.e. quadrant (r / (N/8)) + 2*(j & 1) of its own period.  One ROM read and one
@@ -772,7 +823,8 @@ constexpr int kTaylorRomLds = 4096;     // entries (32 KiB); larger ROMs are rea
 // Each thread takes four consecutive r so that every image is written with one 16-byte store per lane (the dword-per-
 // lane store rate on MI355X is ~4.5 TB/s, the 16-byte rate ~6.9 TB/s: profiles/r01_ubench_gfx950.txt).
 // FAST: both generators take the 1st-order-correction path (PHASE_WIDTH - LUT_SIZE > 3) and the ROM fits LDS -- the usual case.
-template <bool NARROW, uint32_t COMBINE, uint32_t NTERMS, bool FAST>
+// ARITH: 0 generic 64-bit, 1 int32 for dat_width <= 16 (weights inside 16 bits), 2 int32 for dat_width >= 19 with 24 <= 19+L <= 32
+template <int ARITH, uint32_t COMBINE, uint32_t NTERMS, bool FAST>
 __global__ __launch_bounds__(kBlock) void k_taylor_window_fold(BhwTaylorCfg t, BhwWinCfg win, int32_t *__restrict__ out)
 {
     __shared__ int2 rom_s[kTaylorRomLds];
@@ -786,18 +838,29 @@ __global__ __launch_bounds__(kBlock) void k_taylor_window_fold(BhwTaylorCfg t, B
     const int2 *rom_g = reinterpret_cast<const int2 *>(t.rom);
     const uint32_t E = 1u << (t.phi_width - 2);                  // a multiple of 4 (PW >= 5 is required by the caller)
     const uint32_t W = t.dat_width;
-    using val_t = typename std::conditional<NARROW, int32_t, int64_t>::type;
+    constexpr bool NARROW = (ARITH == 1);
+    using val_t = typename std::conditional<ARITH == 2, Sum32, typename std::conditional<ARITH == 1, int32_t, int64_t>::type>::type;
+    using trig_t = typename std::conditional<ARITH == 0, int64_t, int32_t>::type;
     auto add_term = [&](val_t &a, int32_t weight, int32_t v, uint32_t k) {
-        if constexpr (NARROW) {
+        if constexpr (ARITH == 2) {
+            w32_term<COMBINE>(a, weight, v, k, W);
+        } else if constexpr (NARROW) {
             const int32_t m = narrow_term(weight, v, W, COMBINE);
             a += (k & 1u) ? -m : m;
         } else {
             combine_term(a, weight, v, k, W, COMBINE);
         }
     };
-    auto neg = [&](val_t v) -> int32_t {
-        if constexpr (NARROW) return wrap32(-(int32_t)v, W);
+    auto neg = [&](trig_t v) -> int32_t {
+        if constexpr (ARITH != 0) return wrap32(-(int32_t)v, W);
         else return (int32_t)wrap_bits(-(int64_t)v, W);
+    };
+    auto zero = [&]() -> val_t { if constexpr (ARITH == 2) return Sum32{0, 0}; else return (val_t)0; };
+    auto first = [&]() -> val_t {                                 // a_0
+        if constexpr (ARITH == 2) {
+            if constexpr (COMBINE == BHW_COMBINE_HLS) return Sum32{win.aa[0], 0};
+            else return Sum32{win.aa[0] >> 2, win.aa[0] & 3};
+        } else return (val_t)win.aa[0];
     };
     // generators by valuation v = 0, 1, 2 of the harmonic number (k = 1,3,5 | 2,6 | 4)
     BhwTaylorCfg tg[3] = {taylor_gen(t, 0), taylor_gen(t, NTERMS > 2 ? 1 : 0), taylor_gen(t, NTERMS > 4 ? 2 : 0)};
@@ -809,9 +872,10 @@ __global__ __launch_bounds__(kBlock) void k_taylor_window_fold(BhwTaylorCfg t, B
         const BhwTaylorCfg &g = tg[V];
         const uint32_t cnt = (M * r) & ((4u * E >> V) - 1u);
         const uint32_t q0 = (K == 1u) ? 0u : cnt >> (g.phi_width - 2u);
-        val_t s, c;
-        if constexpr (NARROW) { if (in_lds) taylor_q1_narrow(g, rom_s, cnt, s, c); else taylor_q1_narrow(g, rom_g, cnt, s, c); }
-        else                  { if (in_lds) taylor_q1(g, rom_s, cnt, s, c);        else taylor_q1(g, rom_g, cnt, s, c); }
+        trig_t s, c;
+        if constexpr (ARITH == 2)      { taylor_q1_w32(g, rom_s, cnt, s, c); }   // FAST only: ROM in LDS, correction path
+        else if constexpr (NARROW)     { if (in_lds) taylor_q1_narrow(g, rom_s, cnt, s, c); else taylor_q1_narrow(g, rom_g, cnt, s, c); }
+        else                           { if (in_lds) taylor_q1(g, rom_s, cnt, s, c);        else taylor_q1(g, rom_g, cnt, s, c); }
         const int32_t p0 = (int32_t)c, p1 = neg(s), p2 = neg(c), p3 = (int32_t)s;   // quadrant 0..3: taylor_sincos.vhd:240-253
         if constexpr (K == 1u) {
             add_term(acc[0], win.aa[1], p0, 1);
@@ -823,11 +887,11 @@ __global__ __launch_bounds__(kBlock) void k_taylor_window_fold(BhwTaylorCfg t, B
             const int32_t r0 = b0 ? p1 : p0, r1 = b0 ? p2 : p1, r2 = b0 ? p3 : p2, r3 = b0 ? p0 : p3;
             const int32_t sv[4] = {b1 ? r2 : r0, b1 ? r3 : r1, b1 ? r0 : r2, b1 ? r1 : r3};
             if constexpr ((K & 3u) == 0u) {                      // all four images in one quadrant
-                val_t one = 0;
+                val_t one = zero();
                 add_term(one, win.aa[K], sv[0], K);
                 acc[0] += one; acc[1] += one; acc[2] += one; acc[3] += one;
             } else if constexpr ((K & 1u) == 0u) {               // images alternate between two quadrants
-                val_t even = 0, odd = 0;
+                val_t even = zero(), odd = zero();
                 add_term(even, win.aa[K], sv[0], K);
                 add_term(odd, win.aa[K], sv[2], K);
                 acc[0] += even; acc[1] += odd; acc[2] += even; acc[3] += odd;
@@ -845,7 +909,7 @@ __global__ __launch_bounds__(kBlock) void k_taylor_window_fold(BhwTaylorCfg t, B
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t r = r0 + (uint32_t)i;
-        val_t acc[4] = {(val_t)win.aa[0], (val_t)win.aa[0], (val_t)win.aa[0], (val_t)win.aa[0]};
+        val_t acc[4] = {first(), first(), first(), first()};
         harmonic(std::integral_constant<uint32_t, 1>{}, r, acc);
         if constexpr (NTERMS > 2) harmonic(std::integral_constant<uint32_t, 2>{}, r, acc);
         if constexpr (NTERMS > 3) harmonic(std::integral_constant<uint32_t, 3>{}, r, acc);
@@ -856,7 +920,8 @@ __global__ __launch_bounds__(kBlock) void k_taylor_window_fold(BhwTaylorCfg t, B
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if constexpr (NARROW) res[j][i] = narrow_final(acc[j], W, COMBINE, NTERMS);
+            if constexpr (ARITH == 2) res[j][i] = w32_final<COMBINE>(acc[j], W, NTERMS);
+            else if constexpr (NARROW) res[j][i] = narrow_final(acc[j], W, COMBINE, NTERMS);
             else res[j][i] = combine_final(acc[j], W, COMBINE, NTERMS);
         }
     }
@@ -1152,19 +1217,22 @@ int bhwk_taylor_window_fold(const BhwLaunch &l, const BhwTaylorCfg &t, const Bhw
     if (blocks > BHW_TAYLOR_BLOCKS) blocks = BHW_TAYLOR_BLOCKS;
     const dim3 grid(blocks);
     hipStream_t st = (hipStream_t)l.stream;
-#define BHW_TAYLOR_FOLD(NARROW, COMBINE, NT)                                                                        \
+#define BHW_TAYLOR_FOLD(ARITH, COMBINE, NT)                                                                         \
     do {                                                                                                            \
-        if (fast) hipLaunchKernelGGL((k_taylor_window_fold<NARROW, COMBINE, NT, true>), grid, dim3(kBlock), 0, st, t, w, d_out);  \
-        else      hipLaunchKernelGGL((k_taylor_window_fold<NARROW, COMBINE, NT, false>), grid, dim3(kBlock), 0, st, t, w, d_out); \
+        if (fast) hipLaunchKernelGGL((k_taylor_window_fold<ARITH, COMBINE, NT, true>), grid, dim3(kBlock), 0, st, t, w, d_out);  \
+        else      hipLaunchKernelGGL((k_taylor_window_fold<(ARITH == 2 ? 0 : ARITH), COMBINE, NT, false>), grid, dim3(kBlock), 0, st, t, w, d_out); \
     } while (0)
     const bool vhdl = w.combine == BHW_COMBINE_VHDL;
     // every generator in use (PHASE_WIDTH - v, v <= vmax) on the 1st-order-correction path, ROM in LDS
     const int vmax = w.n_terms > 4 ? 2 : w.n_terms > 2 ? 1 : 0;
     const bool fast = (1u << t.lut_size) <= (uint32_t)kTaylorRomLds && (int)t.phi_width - vmax - (int)t.lut_size > 2;
+    // 32-bit arithmetic: int16-sized operands (W <= 16), or the wide rounding variant with its shift inside one mul_hi
+    const int arith = narrow ? 1 : (fast && t.dat_width >= 19 && t.xshift >= 24 && t.xshift <= 32) ? 2 : 0;
 #define BHW_TAYLOR_FOLD_NT(NT)                                                                                      \
     do {                                                                                                            \
-        if (narrow) { if (vhdl) BHW_TAYLOR_FOLD(true, BHW_COMBINE_VHDL, NT);  else BHW_TAYLOR_FOLD(true, BHW_COMBINE_HLS, NT); }  \
-        else        { if (vhdl) BHW_TAYLOR_FOLD(false, BHW_COMBINE_VHDL, NT); else BHW_TAYLOR_FOLD(false, BHW_COMBINE_HLS, NT); } \
+        if (arith == 1)      { if (vhdl) BHW_TAYLOR_FOLD(1, BHW_COMBINE_VHDL, NT); else BHW_TAYLOR_FOLD(1, BHW_COMBINE_HLS, NT); } \
+        else if (arith == 2) { if (vhdl) BHW_TAYLOR_FOLD(2, BHW_COMBINE_VHDL, NT); else BHW_TAYLOR_FOLD(2, BHW_COMBINE_HLS, NT); } \
+        else                 { if (vhdl) BHW_TAYLOR_FOLD(0, BHW_COMBINE_VHDL, NT); else BHW_TAYLOR_FOLD(0, BHW_COMBINE_HLS, NT); } \
     } while (0)
     switch (w.n_terms) {
     case 2: BHW_TAYLOR_FOLD_NT(2); break;
