@@ -74,10 +74,12 @@ __device__ __forceinline__ int64_t wrap_bits(int64_t v, uint32_t bits)
 // instead of one 256-byte piece and two of 128, profiles/r01_ab_inproc.txt.)
 // KCLASS states what the caller knows about u at compile time (from the harmonic number): 0 nothing, 2 u is even,
 // 4 u is a multiple of 4.  Branch-free on purpose: as a ?: chain the compiler emits exec-mask branches per gather.
-template <int KCLASS = 0>
+// SPLIT: -1 decided at run time by `split`, 0 / 1 known at compile time (no branch around the gather: the compiler can then
+// batch the loads of a harmonic instead of waiting on each one).
+template <int KCLASS = 0, int SPLIT = -1>
 __device__ __forceinline__ uint32_t tab_index(uint32_t u, uint32_t log2_entries, uint32_t split)
 {
-    if (!split) return u;
+    if (SPLIT == 0 || (SPLIT < 0 && !split)) return u;
     if constexpr (KCLASS == 4) return u >> 2;
     const uint32_t e = 1u << log2_entries;
     const uint32_t mid = (e >> 2) & (0u - ((u >> 1) & 1u));            // u % 4 == 2 -> second run
@@ -94,11 +96,12 @@ __device__ __forceinline__ uint32_t tab_index(uint32_t u, uint32_t log2_entries,
 // bounds the combine pass, halves.
 constexpr uint32_t kPackLog = 6;
 
-template <int KCLASS = 0, bool COMP = true>
+// FMT: -1 format read from cfg.tab_dlog at run time, 0 plain int2 entries, 1 packed.
+template <int KCLASS = 0, int FMT = -1, int SPLIT = -1>
 __device__ __forceinline__ int2 tab_load(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t log2_entries)
 {
-    const uint32_t idx = tab_index<KCLASS>(u, log2_entries, cfg.tab_split);
-    if (!COMP || cfg.tab_dlog == 0) return reinterpret_cast<const int2 *>(table)[idx];
+    const uint32_t idx = tab_index<KCLASS, SPLIT>(u, log2_entries, cfg.tab_split);
+    if (FMT == 0 || (FMT < 0 && cfg.tab_dlog == 0)) return reinterpret_cast<const int2 *>(table)[idx];
     const uint32_t e = reinterpret_cast<const uint32_t *>(table)[idx];
     const int2 base = reinterpret_cast<const int2 *>(cfg.tab_coarse)[u >> kPackLog];
     return make_int2(base.x + (int32_t)(int16_t)(e & 0xFFFFu), base.y + ((int32_t)e >> 16));
@@ -585,7 +588,8 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(BH
         _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
             _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                             \
                 const uint32_t theta = (uint32_t)K * (rr[b] + (uint32_t)g * H);                          \
-                cs[b][g] = tab_load<KC, COMP>(cfg, table, (theta & emask) >> cfg.z_shr, lq - cfg.z_shr); \
+                cs[b][g] = (NB > 1) ? tab_load<KC, COMP ? 1 : 0, 1>(cfg, table, theta & emask, lq)       \
+                                    : tab_load<KC, COMP ? 1 : 0, -1>(cfg, table, (theta & emask) >> cfg.z_shr, lq - cfg.z_shr); \
             }                                                                                            \
         }                                                                                                \
         _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
