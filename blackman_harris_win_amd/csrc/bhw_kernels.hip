@@ -474,15 +474,17 @@ __global__ __launch_bounds__(kBlock) void k_table_combine_fold(BhwCordicCfg cfg,
 // The 15 run offsets are ~E/15 apart, so tiles m = 0..n_tiles-1 cover the ring once; the few entries
 // covered twice at the seams are recomputed with identical results (idempotent stores).
 // ---------------------------------------------------------------------------------------
+// Tile shape (profiles/r01_ab_inproc.txt): 5 thread groups x 192 lanes.  Thread group p holds the three inv3-siblings of the
+// 15-run tile with i5 = p (24 sums per thread, ~52 VGPRs), so two 960-thread workgroups fit a CU and the gathers of one
+// overlap the arithmetic of the other: 0.1907 ms vs 0.1945 ms for 3 groups x 256 lanes (40 sums per thread, one workgroup per CU).
 #ifndef BHW_TILE_THREADS
-#define BHW_TILE_THREADS 768
+#define BHW_TILE_THREADS 960
 #endif
 #ifndef BHW_TILE_LANES
-#define BHW_TILE_LANES 256
+#define BHW_TILE_LANES 192
 #endif
 #ifndef BHW_TILE_WAVES
-#define BHW_TILE_WAVES 5      // waves per SIMD the tile kernel is register-allocated for: one 768-thread workgroup per CU with
-                              // ~83 VGPRs beats two with 80 and spills (0.2244 vs 0.2323 ms, profiles/r01_ab_inproc.txt)
+#define BHW_TILE_WAVES 8      // waves per SIMD the tile kernel is register-allocated for
 #endif
 constexpr int kTileThreads = BHW_TILE_THREADS;
 constexpr int kTileLanes = BHW_TILE_LANES;     // tile width in lanes; the tile's 15 runs are split over kTileThreads / kTileLanes thread groups
