@@ -1138,9 +1138,10 @@ bool bhwk_tile_applicable(const BhwCordicCfg &c, const BhwWinCfg &w)
     // With dropped phase bits (z_shr > 0) consecutive lanes share table entries, so the gathers are dense on their
     // own: such tables take the one-run form of the kernel over the natural layout.
     if (c.z_shr == 0 && w.combine != BHW_COMBINE_HLS && w.n_terms > 5) return false;
-    // below 2^20 coefficients a tile grid leaves most CUs idle; the one-lane-per-four fold kernel has 8-24x more workgroups
+    // below 2^22 coefficients a grid of 960-thread tiles leaves CUs idle; the one-lane-per-four fold kernel has many more,
+    // smaller workgroups and wins there (2^20: 15.0 vs 18.7 us, 2^21: 20.5 vs 21.2, 2^22: 36.0 vs 25.8; BH-7)
 #ifndef BHW_TILE_MIN_PW
-#define BHW_TILE_MIN_PW 20
+#define BHW_TILE_MIN_PW 22
 #endif
     return c.phi_width >= BHW_TILE_MIN_PW && c.phi_width <= 30;
 }

@@ -84,6 +84,25 @@ def generate(p, n0, count):
     return out
 
 
+_cb = None
+
+
+def generate_mt(p, n0, count, threads=None):
+    """bhwo_generate over host threads (oracle/libcpubaseline.so, the same restatement): for whole windows of 2^22 and up."""
+    global _cb
+    if _cb is None:
+        _cb = ctypes.CDLL(os.path.join(os.path.dirname(ORACLE_SO), "libcpubaseline.so"))
+        _cb.bhw_cpu_baseline.restype = ctypes.c_double
+        _cb.bhw_cpu_baseline.argtypes = [ctypes.c_char_p, ctypes.POINTER(OParams), ctypes.c_uint64, ctypes.c_uint64,
+                                         ctypes.c_int, ctypes.c_void_p]
+    if threads is None:
+        threads = min(16, len(os.sched_getaffinity(0)))
+    out = np.empty(int(count), np.int32)
+    if _cb.bhw_cpu_baseline(None, ctypes.byref(p), int(n0), int(count), threads, out.ctypes.data) < 0:
+        raise ValueError("oracle rejected the parameters")
+    return out
+
+
 def sincos(p, theta0, count):
     s = np.empty(int(count), np.int32)
     c = np.empty(int(count), np.int32)

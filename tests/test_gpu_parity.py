@@ -253,7 +253,7 @@ def test_custom_weights_and_wrapping_sum(torch):
         assert np.array_equal(gpu_generate(p, 0, 1024, algo), O.generate(O.from_bhw(p), 0, 1024))
 
 
-# ---- whole-period calls: fold kernel below 2^20 coefficients, gather tiles (1-, 3-, 15-run; 32/64-bit sums) from 2^20 ----
+# ---- whole-period calls: fold kernel below 2^22 coefficients, gather tiles (1-, 3-, 15-run; 32/64-bit sums) from 2^22 ----
 TILE_CASES = [(1, 16, 16, B.MODEL_HLS, B.COMBINE_HLS), (3, 16, 24, B.MODEL_HLS, B.COMBINE_VHDL),
               (4, 17, 24, B.MODEL_CPP, B.COMBINE_HLS), (5, 16, 32, B.MODEL_HLS, B.COMBINE_HLS),
               (7, 16, 32, B.MODEL_VHDL, B.COMBINE_VHDL), (7, 17, 30, B.MODEL_CPP, B.COMBINE_VHDL),
@@ -262,16 +262,20 @@ TILE_CASES = [(1, 16, 16, B.MODEL_HLS, B.COMBINE_HLS), (3, 16, 24, B.MODEL_HLS, 
               # phase bits dropped (PW >= W): small shared table, one-run form of the tile kernel
               (7, 20, 12, B.MODEL_CPP, B.COMBINE_HLS), (7, 18, 16, B.MODEL_VHDL, B.COMBINE_VHDL),
               (5, 19, 14, B.MODEL_CPP, B.COMBINE_VHDL), (4, 18, 16, B.MODEL_HLS, B.COMBINE_HLS),
-              # N >= 2^20: tile kernel proper (1-, 3-run tiles, 64-bit sums, dropped phase bits)
-              (1, 20, 16, B.MODEL_CPP, B.COMBINE_HLS), (3, 20, 24, B.MODEL_HLS, B.COMBINE_VHDL),
-              (5, 20, 30, B.MODEL_VHDL, B.COMBINE_VHDL), (7, 21, 12, B.MODEL_CPP, B.COMBINE_VHDL)]
+              # 2^20, 2^21: still the fold kernel (the 960-thread tiles only win from 2^22 on)
+              (1, 20, 16, B.MODEL_CPP, B.COMBINE_HLS), (7, 21, 12, B.MODEL_CPP, B.COMBINE_VHDL),
+              # N >= 2^22: tile kernel proper (1-, 3-, 15-run tiles; 32- and 64-bit sums; plain and packed tables; dropped phase bits)
+              (1, 22, 16, B.MODEL_CPP, B.COMBINE_HLS), (3, 22, 24, B.MODEL_HLS, B.COMBINE_VHDL),
+              (5, 22, 30, B.MODEL_VHDL, B.COMBINE_VHDL), (7, 22, 12, B.MODEL_CPP, B.COMBINE_VHDL),
+              (7, 22, 30, B.MODEL_HLS, B.COMBINE_HLS), (7, 23, 32, B.MODEL_CPP, B.COMBINE_HLS),
+              (7, 22, 32, B.MODEL_VHDL, B.COMBINE_HLS), (4, 22, 32, B.MODEL_HLS, B.COMBINE_HLS)]
 
 
 @pytest.mark.parametrize("win,pw,w,model,combine", TILE_CASES)
 def test_whole_period_tile_path(torch, win, pw, w, model, combine):
     p = B.make_params(win, pw, w, model=model, combine=combine)
     n = 1 << pw
-    want = O.generate(O.from_bhw(p), 0, n)
+    want = O.generate_mt(O.from_bhw(p), 0, n)
     assert np.array_equal(gpu_generate(p, 0, n, B.ALGO_TABLE), want)
     # two periods: the second is the store-only replica of the first
     two = gpu_generate(p, n, 2 * n, B.ALGO_TABLE)
@@ -318,11 +322,12 @@ def test_ragged_counts_and_offsets(torch, algo):
     (7, 12, 32, B.MODEL_HLS, 1000, 3 * 4096 + 123),            # head + 2 periods (fold + replicate) + tail
     (4, 10, 24, B.MODEL_CPP, 1023, 1025),                       # 1-sample head, one period, no tail
     (5, 11, 16, B.MODEL_VHDL, 2048 * 7 + 1, 2047 + 2048),       # head + exactly one period
-    (7, 20, 32, B.MODEL_HLS, 12345, (1 << 20) + (1 << 19)),     # tile kernel in the middle of a ragged range
+    (7, 20, 32, B.MODEL_HLS, 12345, (1 << 20) + (1 << 19)),     # fold kernel in the middle of a ragged range
+    (7, 22, 30, B.MODEL_HLS, 54321, (1 << 22) + (1 << 20)),     # tile kernel (packed table) in the middle of a ragged range
 ])
 def test_ragged_range_spanning_whole_periods(torch, win, pw, w, model, n0, count):
     p = B.make_params(win, pw, w, model=model)
-    want = O.generate(O.from_bhw(p), n0, count)
+    want = O.generate_mt(O.from_bhw(p), n0, count)
     assert np.array_equal(gpu_generate(p, n0, count, B.ALGO_TABLE), want)
 
 
@@ -494,7 +499,7 @@ def test_packed_table_is_exact(torch, golden):
         "import hashlib, sys; sys.path.insert(0, %r)\n"
         "import blackman_harris_win_amd as bhw\n"
         "from blackman_harris_win_amd import binding as B\n"
-        "for win, pw, w, model in ((7, 26, 32, 0), (7, 24, 32, 1), (4, 22, 24, 2), (5, 21, 29, 0), (7, 20, 28, 2), (3, 22, 30, 0)):\n"
+        "for win, pw, w, model in ((7, 26, 32, 0), (7, 24, 32, 1), (4, 22, 24, 2), (5, 23, 29, 0), (7, 22, 28, 2), (3, 22, 30, 0)):\n"
         "    p = B.make_params(win, pw, w, model=model)\n"
         "    a = bhw.generate(p, 12345, (1 << pw) + 99999, algo=B.ALGO_TABLE).cpu().numpy()\n"
         "    print(hashlib.md5(a.tobytes()).hexdigest())\n" % ROOT)
