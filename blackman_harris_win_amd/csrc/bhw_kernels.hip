@@ -497,10 +497,11 @@ struct BhwTilePlan {
 // MODE 0: HLS cosine-sum, two's-complement quadrant map, sums kept modulo 2^32 (exact: the result is
 //         wrapped to W <= 32 bits anyway, win_function.cpp:375);  MODE 1: same with the one's-complement map of
 //         the cpp model;  MODE 2: any combine rule, 64-bit sums (the VHDL rule needs W+2 bits).
+// sv[i] = the harmonic's term for an image whose quadrant is q + i
 template <int K, int MODE>
 __device__ __forceinline__ void tile_harmonic(const BhwCordicCfg &cfg, const int32_t a, const uint32_t W, const uint32_t combine,
                                               const int2 cs, const uint32_t q,
-                                              typename std::conditional<MODE == 2, int64_t, int32_t>::type (&acc)[4])
+                                              typename std::conditional<MODE == 2, int64_t, int32_t>::type (&sv)[4])
 {
     using acc_t = typename std::conditional<MODE == 2, int64_t, int32_t>::type;
     acc_t p0, p1, p2, p3;                                  // cosine term in quadrant 0..3: c, -s, -c, s
@@ -538,12 +539,20 @@ __device__ __forceinline__ void tile_harmonic(const BhwCordicCfg &cfg, const int
     // rotate the four candidates by q so that image j (quadrant q + j*K) reads a fixed slot
     const bool b0 = q & 1u, b1 = q & 2u;
     const acc_t r0 = b0 ? p1 : p0, r1 = b0 ? p2 : p1, r2 = b0 ? p3 : p2, r3 = b0 ? p0 : p3;
-    const acc_t s0 = b1 ? r2 : r0, s1 = b1 ? r3 : r1, s2 = b1 ? r0 : r2, s3 = b1 ? r1 : r3;
-    const acc_t sv[4] = {s0, s1, s2, s3};
-    acc[0] += sv[0];
-    acc[1] += sv[K & 3];
-    acc[2] += sv[(2 * K) & 3];
-    acc[3] += sv[(3 * K) & 3];
+    sv[0] = b1 ? r2 : r0;
+    sv[1] = b1 ? r3 : r1;
+    sv[2] = b1 ? r0 : r2;
+    sv[3] = b1 ? r1 : r3;
+}
+
+// image j of a lane sits K*j quadrants after image 0; OFF = extra quadrants of this half-period image (even K: K/2)
+template <int K, int OFF, typename acc_t>
+__device__ __forceinline__ void tile_accumulate(const acc_t (&sv)[4], acc_t (&acc)[4])
+{
+    acc[0] += sv[OFF & 3];
+    acc[1] += sv[(K + OFF) & 3];
+    acc[2] += sv[(2 * K + OFF) & 3];
+    acc[3] += sv[(3 * K + OFF) & 3];
 }
 
 // Lane r in [0, E/2) owns the eight coefficients n = r + h*E/2 + j*E (h = 0,1; j = 0..3).  For even k the
@@ -595,9 +604,16 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(BH
             }                                                                                            \
         }                                                                                                \
         _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
-            _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                              \
-                const uint32_t theta = (uint32_t)K * (rr[b] + (uint32_t)h * H);   /* only quadrant bits 0,1 are used */ \
-                tile_harmonic<K, MODE>(cfg, win.aa[K], W, win.combine, cs[b][NG == 2 ? h : 0], theta >> lq, acc[b][h]); \
+            acc_t sv[4];                                                                                 \
+            /* only quadrant bits 0,1 of theta >> lq are used */                                         \
+            tile_harmonic<K, MODE>(cfg, win.aa[K], W, win.combine, cs[b][0], ((uint32_t)K * rr[b]) >> lq, sv); \
+            tile_accumulate<K, 0>(sv, acc[b][0]);                                                        \
+            if constexpr (NG == 2) {                                                                     \
+                tile_harmonic<K, MODE>(cfg, win.aa[K], W, win.combine, cs[b][NG - 1], ((uint32_t)K * (rr[b] + H)) >> lq, sv); \
+                tile_accumulate<K, 0>(sv, acc[b][1]);                                                    \
+            } else {                                                                                     \
+                /* even K: the second half-period image reads the same entry K/2 quadrants further on */ \
+                tile_accumulate<K, K / 2>(sv, acc[b][1]);                                                \
             }                                                                                            \
         }                                                                                                \
     }
