@@ -60,6 +60,20 @@ def main():
         pt = bhw.make_params(win, 26, w, sin_type=B.SIN_TAYLOR, combine=B.COMBINE_VHDL, lut_size=9)
         ms = timeit(lambda: bhw.generate(pt, 0, 1 << 26, out=o3), iters=10, warm=2)
         res[f"taylor_{name}_2^26"] = {"ms": ms, "Gsamples/s": (1 << 26) / ms / 1e6, "GB/s": 4 * (1 << 26) / ms / 1e6}
+    for name, w, comb in (("hlsrule_32bit", 32, B.COMBINE_HLS), ("vhdlrule_32bit", 32, B.COMBINE_VHDL), ("hlsrule_16bit", 16, B.COMBINE_HLS)):
+        pt = bhw.make_params(7, 26, w, sin_type=B.SIN_TAYLOR_ALL, combine=comb, lut_size=9)
+        ms = timeit(lambda: bhw.generate(pt, 0, 1 << 26, out=o3), iters=10, warm=2)
+        res[f"taylor_all_bh7_{name}_2^26"] = {"ms": ms, "Gsamples/s": (1 << 26) / ms / 1e6, "GB/s": 4 * (1 << 26) / ms / 1e6,
+                                              "note": "extension BHW_SIN_TAYLOR_ALL (no reference counterpart)"}
+    for name, model in (("dds48", B.MODEL_DDS48), ("scaled", B.MODEL_SCALED)):
+        pv = bhw.make_params(1, 26, 32, model=model)
+        ms = timeit(lambda: bhw.cordic(pv, 0, 1 << 26), iters=3, warm=1)
+        res[f"sincos_{name}_2^26_32bit"] = {"ms": ms, "Gphases/s": (1 << 26) / ms / 1e6}
+    ax = torch.randint(-(1 << 22), 1 << 22, (1 << 26,), dtype=torch.int32, device="cuda")
+    ay = torch.randint(-(1 << 22), 1 << 22, (1 << 26,), dtype=torch.int32, device="cuda")
+    ms = timeit(lambda: bhw.atan2(ax, ay, PRECISION=2, INPUT_WIDTH=23, ANGLE_WIDTH=24, out=o3), iters=3, warm=1)
+    res["atan2_2^26_p2_23_24"] = {"ms": ms, "Gpairs/s": (1 << 26) / ms / 1e6, "GB/s": 12 * (1 << 26) / ms / 1e6}
+    del ax, ay
     pc = bhw.make_params(1, 26, 32, model=B.MODEL_CPP)
     ms = timeit(lambda: bhw.cordic(pc, 0, 1 << 26), iters=5, warm=1)
     res["sincos_cpp_2^26_32bit"] = {"ms": ms, "Gphases/s": (1 << 26) / ms / 1e6}
