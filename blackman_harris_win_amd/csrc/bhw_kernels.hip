@@ -1274,29 +1274,54 @@ int bhwk_taylor_window_fold(const BhwLaunch &l, const BhwTaylorCfg &t, const Bhw
 // Variant generators.  One lane per sample, 64-bit state wrapped to the entity's vector widths.
 // ---------------------------------------------------------------------------------------
 // cordic_dds48 (src/cordic_dds48.vhd:160-258) and cordic_dds_scaled (src/cordic_dds_scaled.vhd:176-283)
+// The SIZE- and DWPH-bit stores of the entities never wrap (|x|, |y| <= 2^(SIZE-2) * 1.0000..., |z| < 2^(DWPH-2) + atan
+// terms; tests/test_oracle.py::test_variant_generator_wraps_never_fire), so the kernel keeps plain 64-bit state.
+// Rotation ii in "mad" form once the shifted operand fits 32 bits (SIZE <= 48: ii >= 16), as in rot_step; the first
+// rotations use 64-bit select-and-add.  dds48 :233-251: z >= 0 -> x += y>>ii, y -= x>>ii, z -= rom; else the opposite.
+template <int II>
+__device__ __forceinline__ void prerot_step(int64_t &x, int64_t &y, int64_t &z, int64_t rom, bool last)
+{
+    const int32_t m = (int32_t)(z >> 63);               // -1 when z < 0
+    if constexpr (II >= 16) {
+        const int32_t sg = m | 1;                       // -1 when z < 0, +1 otherwise
+        const int32_t nsg = -sg;
+        int32_t ys = (int32_t)(y >> II), xs = (int32_t)(x >> II);
+        asm volatile("" : "+v"(ys), "+v"(xs));          // both shifts read the old state
+        x += (int64_t)sg * (int64_t)ys;
+        y += (int64_t)nsg * (int64_t)xs;
+        if (!last) z += (int64_t)nsg * (int64_t)(int32_t)rom;       // rom < 2^(45-II) here
+    } else {
+        const int64_t ys = y >> II, xs = x >> II;
+        const bool neg = m != 0;
+        x += neg ? -ys : ys;
+        y += neg ? xs : -xs;
+        if (!last) z += neg ? rom : -rom;
+    }
+}
+
+template <int NITER>
 __global__ __launch_bounds__(kBlock) void k_sincos_prerot(BhwPrerotCfg c, uint64_t theta0, uint64_t count,
                                                            int32_t *__restrict__ d_sin, int32_t *__restrict__ d_cos)
 {
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= count) return;
-    const uint32_t PW = c.phi_width, W = c.dat_width;
+    const uint32_t PW = c.phi_width;
     const uint64_t theta = (theta0 + i) & ((1ull << PW) - 1ull);
     const uint32_t q = (uint32_t)(theta >> (PW - 2)) & 3u;              // dds48 :167
     const uint64_t low = theta & ((1ull << (PW - 2)) - 1ull);
     uint64_t t = theta;                                                 // init_t :169-186
     int64_t x = c.gain, y = 0;                                          // init_x / init_y :191-216
-    if (q == 1u)      { t = low;                      x = 0; y = wrap_bits(-c.gain, c.size); }
+    if (q == 1u)      { t = low;                      x = 0; y = -c.gain; }
     else if (q == 2u) { t = (3ull << (PW - 2)) | low; x = 0; y = c.gain; }
-    int64_t z = wrap_bits((int64_t)(t << (c.dwph - PW)), c.dwph);       // init_z :163-164 (scaled :180-186)
-    for (uint32_t ii = 0; ii < W; ++ii) {                               // :233-251
-        const int64_t xs = x >> ii, ys = y >> ii;
-        const bool pos = z >= 0;
-        x = wrap_bits(pos ? x + ys : x - ys, c.size);
-        y = wrap_bits(pos ? y - xs : y + xs, c.size);
-        if (ii + 1 < W) z = wrap_bits(pos ? z - c.lut[ii] : z + c.lut[ii], c.dwph);
-    }
-    if (d_sin) d_sin[i] = (int32_t)(y >> (c.size - W));                 // :257-258
-    if (d_cos) d_cos[i] = (int32_t)(x >> (c.size - W));
+    int64_t z = wrap_bits((int64_t)(t << (c.dwph - PW)), c.dwph);       // init_z :163-164 (scaled :180-186): sign-extend the phase
+#define BHW_PREROT(II) if constexpr (NITER > II) prerot_step<II>(x, y, z, c.lut[II], II + 1 == NITER);
+    BHW_PREROT(0) BHW_PREROT(1) BHW_PREROT(2) BHW_PREROT(3) BHW_PREROT(4) BHW_PREROT(5) BHW_PREROT(6) BHW_PREROT(7)
+    BHW_PREROT(8) BHW_PREROT(9) BHW_PREROT(10) BHW_PREROT(11) BHW_PREROT(12) BHW_PREROT(13) BHW_PREROT(14) BHW_PREROT(15)
+    BHW_PREROT(16) BHW_PREROT(17) BHW_PREROT(18) BHW_PREROT(19) BHW_PREROT(20) BHW_PREROT(21) BHW_PREROT(22) BHW_PREROT(23)
+    BHW_PREROT(24) BHW_PREROT(25) BHW_PREROT(26) BHW_PREROT(27) BHW_PREROT(28) BHW_PREROT(29) BHW_PREROT(30) BHW_PREROT(31)
+#undef BHW_PREROT
+    if (d_sin) d_sin[i] = (int32_t)(y >> (c.size - NITER));             // :257-258  top DATA_WIDTH bits
+    if (d_cos) d_cos[i] = (int32_t)(x >> (c.size - NITER));
 }
 
 // cordic_atan2 (src/cordic_atan2.vhd:126-213)
@@ -1331,7 +1356,16 @@ int bhwk_sincos_prerot(const BhwLaunch &l, const BhwPrerotCfg &c, uint64_t theta
 {
     if (!count) return 0;
     BHW_SET_DEVICE(l);
-    hipLaunchKernelGGL(k_sincos_prerot, dim3(grid_for(count)), dim3(kBlock), 0, (hipStream_t)l.stream, c, theta0, count, d_sin, d_cos);
+    const dim3 grid(grid_for(count)), block(kBlock);
+    hipStream_t st = (hipStream_t)l.stream;
+    switch (c.dat_width) {                                              // DATA_WIDTH stages, unrolled
+#define BHW_CASE(N) case N: hipLaunchKernelGGL(k_sincos_prerot<N>, grid, block, 0, st, c, theta0, count, d_sin, d_cos); break;
+        BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14) BHW_CASE(15) BHW_CASE(16)
+        BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20) BHW_CASE(21) BHW_CASE(22) BHW_CASE(23) BHW_CASE(24)
+        BHW_CASE(25) BHW_CASE(26) BHW_CASE(27) BHW_CASE(28) BHW_CASE(29) BHW_CASE(30) BHW_CASE(31) BHW_CASE(32)
+#undef BHW_CASE
+    default: return (int)hipErrorInvalidValue;
+    }
     return finish(hipSuccess);
 }
 

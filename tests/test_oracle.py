@@ -245,6 +245,25 @@ def test_variant_goldens_reproduce(golden, golden_dir):
             assert md5(O.generate(p, e["n0"], e["count"])) == e["md5"]
 
 
+def test_variant_generator_wraps_never_fire():
+    """The SIZE- / DWPH-bit stores of cordic_dds48 and cordic_dds_scaled never change a value (k_sincos_prerot omits them)."""
+    import ctypes
+    o = O.oracle()
+    ev = ctypes.c_uint64(0)
+    c = np.empty(1, np.int32)
+    s = np.empty(1, np.int32)
+    rng = np.random.default_rng(11)
+    for model in (O.MODEL_DDS48, O.MODEL_SCALED):
+        for pw, w in [(10, 8), (10, 16), (12, 12), (18, 16), (20, 24), (26, 32), (30, 9), (30, 30), (9, 32), (32, 21), (4, 10)]:
+            n = 1 << pw
+            th = np.arange(n) if pw <= 12 else np.unique(np.concatenate(
+                [rng.integers(0, n, 2500), np.arange(64), n - 1 - np.arange(64)] +
+                [q * (n // 4) + np.arange(-64, 64) for q in range(1, 4)] + [n // 8 + np.arange(-8, 8)]) % n)
+            for t in th:
+                assert o.bhwo_cordic(model, pw, w, 1, int(t), c.ctypes.data, s.ctypes.data, ctypes.byref(ev)) == 0
+    assert ev.value == 0
+
+
 def test_dds48_is_the_48_bit_case_of_scaled():
     """SEL_SIZE(DATA_WIDTH-8) = 48 from DATA_WIDTH = 29 on (src/cordic_dds_scaled.vhd:102-107): both entities agree there."""
     for w in (29, 30, 32):
