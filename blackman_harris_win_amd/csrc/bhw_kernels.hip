@@ -494,25 +494,66 @@ struct BhwTilePlan {
     uint32_t n_tiles;
 };
 
+__device__ __forceinline__ int32_t wrap32(int32_t v, uint32_t bits)
+{
+    const uint32_t sh = 32u - bits;
+    return (int32_t)((uint32_t)v << sh) >> sh;
+}
+
+
+// W-bit sums of the cosine-sum rules in 32-bit registers.  HLS rule: everything modulo 2^32, wrapped to W bits at the end.
+// VHDL rule: the sum needs W+2 bits, so it is carried as S = 4*hi + lo (hi modulo 2^32, lo a small exact integer):
+//   b_k = wrap_W((P >> (W-1)) + ((P >> (W-2)) & 1))   == the slice-and-round of bh_win_7term.vhd:353-402 on the 2W-bit product P
+//   S>>2 = hi + (lo>>2),  (S>>1)&1 = (lo>>1)&1,  S>>1 = 2*hi + (lo>>1),  S&1 = lo&1
+struct Sum32 {
+    int32_t hi, lo;
+    __device__ __forceinline__ Sum32 &operator+=(const Sum32 &o) { hi += o.hi; lo += o.lo; return *this; }
+};
+
+template <uint32_t COMBINE>
+__device__ __forceinline__ void w32_term(Sum32 &acc, int32_t a, int32_t v, uint32_t k, uint32_t W)
+{
+    const int64_t P = (int64_t)a * (int64_t)v;
+    if constexpr (COMBINE == BHW_COMBINE_HLS) {
+        const int32_t m = (int32_t)(P >> (W - 2));
+        acc.hi += (k & 1u) ? -m : m;
+    } else {
+        const int32_t b = wrap32((int32_t)(P >> (W - 1)) + (int32_t)(((uint32_t)P >> (W - 2)) & 1u), W);
+        if (k & 1u) { acc.hi -= b >> 2; acc.lo -= b & 3; }
+        else        { acc.hi += b >> 2; acc.lo += b & 3; }
+    }
+}
+
+template <uint32_t COMBINE>
+__device__ __forceinline__ int32_t w32_final(const Sum32 &acc, uint32_t W, uint32_t n_terms)
+{
+    if constexpr (COMBINE == BHW_COMBINE_HLS) return wrap32(acc.hi, W);
+    else if (n_terms == 2) return wrap32(2 * acc.hi + (acc.lo >> 1) + (acc.lo & 1), W);          // hamming_win.vhd:214-228
+    else return wrap32(acc.hi + (acc.lo >> 2) + ((acc.lo >> 1) & 1), W);                         // bh_win_7term.vhd:409-435
+}
+
 // MODE 0: HLS cosine-sum, two's-complement quadrant map, sums kept modulo 2^32 (exact: the result is
 //         wrapped to W <= 32 bits anyway, win_function.cpp:375);  MODE 1: same with the one's-complement map of
-//         the cpp model;  MODE 2: any combine rule, 64-bit sums (the VHDL rule needs W+2 bits).
-// sv[i] = the harmonic's term for an image whose quadrant is q + i
+//         the cpp model;  MODE 2: VHDL cosine-sum (either quadrant map): per-product slice-and-round b_k in 32 bits, the
+//         W+2-bit sum carried as 4*hi + lo (Sum32 above).
+// sv[i] = the harmonic's term for an image whose quadrant is q + i (MODE 0/1: already signed (-1)^K; MODE 2: b_k, sign applied
+// when it is accumulated)
 template <int K, int MODE>
-__device__ __forceinline__ void tile_harmonic(const BhwCordicCfg &cfg, const int32_t a, const uint32_t W, const uint32_t combine,
-                                              const int2 cs, const uint32_t q,
-                                              typename std::conditional<MODE == 2, int64_t, int32_t>::type (&sv)[4])
+__device__ __forceinline__ void tile_harmonic(const BhwCordicCfg &cfg, const int32_t a, const uint32_t W, const int2 cs, const uint32_t q,
+                                              int32_t (&sv)[4])
 {
-    using acc_t = typename std::conditional<MODE == 2, int64_t, int32_t>::type;
-    acc_t p0, p1, p2, p3;                                  // cosine term in quadrant 0..3: c, -s, -c, s
+    int32_t p0, p1, p2, p3;                                // cosine term in quadrant 0..3: c, -s, -c, s
     if constexpr (MODE == 2) {
         const int32_t nc = cfg.ones_neg ? ~cs.x : -cs.x;
         const int32_t ns = cfg.ones_neg ? ~cs.y : -cs.y;
-        p0 = p1 = p2 = p3 = 0;
-        combine_term(p0, a, cs.x, K, W, combine);
-        combine_term(p1, a, ns, K, W, combine);
-        combine_term(p2, a, nc, K, W, combine);
-        combine_term(p3, a, cs.y, K, W, combine);
+        auto slice_round = [&](int32_t v) -> int32_t {     // bh_win_7term.vhd:353-402 on the 2W-bit product (see Sum32)
+            const int64_t P = (int64_t)a * (int64_t)v;
+            return wrap32((int32_t)(P >> (W - 1)) + (int32_t)(((uint32_t)P >> (W - 2)) & 1u), W);
+        };
+        p0 = slice_round(cs.x);
+        p1 = slice_round(ns);
+        p2 = slice_round(nc);
+        p3 = slice_round(cs.y);
     } else {
         const uint32_t sh = W - 2;                         // mlt_k = (a_k * c_k) >> (NWIDTH-2), win_function.cpp:368-373
         if constexpr (MODE == 1) {
@@ -538,7 +579,7 @@ __device__ __forceinline__ void tile_harmonic(const BhwCordicCfg &cfg, const int
     }
     // rotate the four candidates by q so that image j (quadrant q + j*K) reads a fixed slot
     const bool b0 = q & 1u, b1 = q & 2u;
-    const acc_t r0 = b0 ? p1 : p0, r1 = b0 ? p2 : p1, r2 = b0 ? p3 : p2, r3 = b0 ? p0 : p3;
+    const int32_t r0 = b0 ? p1 : p0, r1 = b0 ? p2 : p1, r2 = b0 ? p3 : p2, r3 = b0 ? p0 : p3;
     sv[0] = b1 ? r2 : r0;
     sv[1] = b1 ? r3 : r1;
     sv[2] = b1 ? r0 : r2;
@@ -546,23 +587,33 @@ __device__ __forceinline__ void tile_harmonic(const BhwCordicCfg &cfg, const int
 }
 
 // image j of a lane sits K*j quadrants after image 0; OFF = extra quadrants of this half-period image (even K: K/2)
-template <int K, int OFF, typename acc_t>
-__device__ __forceinline__ void tile_accumulate(const acc_t (&sv)[4], acc_t (&acc)[4])
+template <int K, int OFF>
+__device__ __forceinline__ void tile_accumulate(const int32_t (&sv)[4], int32_t (&acc)[4])
 {
     acc[0] += sv[OFF & 3];
     acc[1] += sv[(K + OFF) & 3];
     acc[2] += sv[(2 * K + OFF) & 3];
     acc[3] += sv[(3 * K + OFF) & 3];
 }
+template <int K, int OFF>
+__device__ __forceinline__ void tile_accumulate(const int32_t (&sv)[4], Sum32 (&acc)[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int32_t b = sv[(j * K + OFF) & 3];
+        if (K & 1) { acc[j].hi -= b >> 2; acc[j].lo -= b & 3; }
+        else       { acc[j].hi += b >> 2; acc[j].lo += b & 3; }
+    }
+}
 
 // Lane r in [0, E/2) owns the eight coefficients n = r + h*E/2 + j*E (h = 0,1; j = 0..3).  For even k the
 // two h-images share one gather (k*E/2 is a whole number of quadrants); for odd k the second image reads
 // entry t + E/2, another dense span of the same tile.
 template <int NB, int MODE, bool COMP>
-__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(BHW_TILE_WAVES))) void k_table_combine_tile(BhwCordicCfg cfg, BhwWinCfg win, BhwTilePlan tp,
+__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 4 : BHW_TILE_WAVES))) void k_table_combine_tile(BhwCordicCfg cfg, BhwWinCfg win, BhwTilePlan tp,
                                                                       const void *__restrict__ table, int32_t *__restrict__ out)
 {
-    using acc_t = typename std::conditional<MODE == 2, int64_t, int32_t>::type;
+    using acc_t = typename std::conditional<MODE == 2, Sum32, int32_t>::type;
     const uint32_t lq = cfg.phi_width - 2;
     const uint32_t E = 1u << lq, emask = E - 1u, H = E >> 1, hmask = H - 1u;
     const uint32_t W = cfg.dat_width;
@@ -589,7 +640,10 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(BH
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[b][h][j] = (acc_t)win.aa[0];
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (MODE == 2) acc[b][h][j] = Sum32{win.aa[0] >> 2, win.aa[0] & 3};
+                else acc[b][h][j] = win.aa[0];
+            }
 
 #define BHW_TILE_HARMONIC(K)                                                                             \
     if (win.n_terms > K) {                                                                               \
@@ -604,12 +658,12 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(BH
             }                                                                                            \
         }                                                                                                \
         _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
-            acc_t sv[4];                                                                                 \
+            int32_t sv[4];                                                                               \
             /* only quadrant bits 0,1 of theta >> lq are used */                                         \
-            tile_harmonic<K, MODE>(cfg, win.aa[K], W, win.combine, cs[b][0], ((uint32_t)K * rr[b]) >> lq, sv); \
+            tile_harmonic<K, MODE>(cfg, win.aa[K], W, cs[b][0], ((uint32_t)K * rr[b]) >> lq, sv);       \
             tile_accumulate<K, 0>(sv, acc[b][0]);                                                        \
             if constexpr (NG == 2) {                                                                     \
-                tile_harmonic<K, MODE>(cfg, win.aa[K], W, win.combine, cs[b][NG - 1], ((uint32_t)K * (rr[b] + H)) >> lq, sv); \
+                tile_harmonic<K, MODE>(cfg, win.aa[K], W, cs[b][NG - 1], ((uint32_t)K * (rr[b] + H)) >> lq, sv); \
                 tile_accumulate<K, 0>(sv, acc[b][1]);                                                    \
             } else {                                                                                     \
                 /* even K: the second half-period image reads the same entry K/2 quadrants further on */ \
@@ -633,7 +687,7 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(BH
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 int32_t v;
-                if constexpr (MODE == 2) v = combine_final((int64_t)acc[b][h][j], W, win.combine, win.n_terms);
+                if constexpr (MODE == 2) v = w32_final<BHW_COMBINE_VHDL>(acc[b][h][j], W, win.n_terms);
                 else v = (int32_t)((uint32_t)acc[b][h][j] << (32u - W)) >> (32u - W);   // (win_t)(...) wrap to W bits
                 emit(win, out, r + (uint32_t)h * H + (uint32_t)j * E, v);
             }
@@ -722,13 +776,7 @@ __device__ __forceinline__ BhwTaylorCfg taylor_gen(const BhwTaylorCfg &t, uint32
     return g;
 }
 
-// ---- 32-bit forms for dat_width <= 16 (every product a*v and every sum fits int32; same results) ----
-__device__ __forceinline__ int32_t wrap32(int32_t v, uint32_t bits)
-{
-    const uint32_t sh = 32u - bits;
-    return (int32_t)((uint32_t)v << sh) >> sh;
-}
-
+// ---- 32-bit forms for dat_width <= 16 (every product a*v and every sum fits int32; same results; wrap32 is defined above) ----
 __device__ __forceinline__ void taylor_q1_narrow(const BhwTaylorCfg &t, const int2 *rom, uint32_t cnt, int32_t &s, int32_t &c)
 {
     const uint32_t pw = t.phi_width, W = t.dat_width, L = t.lut_size;
@@ -803,37 +851,6 @@ __device__ __forceinline__ void taylor_q1_w32(const BhwTaylorCfg &t, const int2 
     s = wrap32((int32_t)((uint32_t)sc.x + (uint32_t)ds), W);
     if (c < 0) c = sat;                                                         // :602-616
     if (s < 0) s = sat;
-}
-
-// W-bit sums of the cosine-sum rules in 32-bit registers.  HLS rule: everything modulo 2^32, wrapped to W bits at the end.
-// VHDL rule: the sum needs W+2 bits, so it is carried as S = 4*hi + lo (hi modulo 2^32, lo a small exact integer):
-//   b_k = wrap_W((P >> (W-1)) + ((P >> (W-2)) & 1))   == the slice-and-round of bh_win_7term.vhd:353-402 on the 2W-bit product P
-//   S>>2 = hi + (lo>>2),  (S>>1)&1 = (lo>>1)&1,  S>>1 = 2*hi + (lo>>1),  S&1 = lo&1
-struct Sum32 {
-    int32_t hi, lo;
-    __device__ __forceinline__ Sum32 &operator+=(const Sum32 &o) { hi += o.hi; lo += o.lo; return *this; }
-};
-
-template <uint32_t COMBINE>
-__device__ __forceinline__ void w32_term(Sum32 &acc, int32_t a, int32_t v, uint32_t k, uint32_t W)
-{
-    const int64_t P = (int64_t)a * (int64_t)v;
-    if constexpr (COMBINE == BHW_COMBINE_HLS) {
-        const int32_t m = (int32_t)(P >> (W - 2));
-        acc.hi += (k & 1u) ? -m : m;
-    } else {
-        const int32_t b = wrap32((int32_t)(P >> (W - 1)) + (int32_t)(((uint32_t)P >> (W - 2)) & 1u), W);
-        if (k & 1u) { acc.hi -= b >> 2; acc.lo -= b & 3; }
-        else        { acc.hi += b >> 2; acc.lo += b & 3; }
-    }
-}
-
-template <uint32_t COMBINE>
-__device__ __forceinline__ int32_t w32_final(const Sum32 &acc, uint32_t W, uint32_t n_terms)
-{
-    if constexpr (COMBINE == BHW_COMBINE_HLS) return wrap32(acc.hi, W);
-    else if (n_terms == 2) return wrap32(2 * acc.hi + (acc.lo >> 1) + (acc.lo & 1), W);          // hamming_win.vhd:214-228
-    else return wrap32(acc.hi + (acc.lo >> 2) + ((acc.lo >> 1) & 1), W);                         // bh_win_7term.vhd:409-435
 }
 
 // Whole-period Taylor window, quadrant fold: lane r in [0, N/4) owns n = r + j*N/4.  The first generator's quadrant
@@ -1150,10 +1167,9 @@ static uint32_t inv_mod_pow2(uint32_t a, uint32_t log2m)
 
 bool bhwk_tile_applicable(const BhwCordicCfg &c, const BhwWinCfg &w)
 {
-    // the 15-run tile with 64-bit sums (VHDL rule at 6+ harmonics) does not fit the register file: plain fold instead
     // With dropped phase bits (z_shr > 0) consecutive lanes share table entries, so the gathers are dense on their
     // own: such tables take the one-run form of the kernel over the natural layout.
-    if (c.z_shr == 0 && w.combine != BHW_COMBINE_HLS && w.n_terms > 5) return false;
+    (void)w;
     // below 2^22 coefficients a grid of 960-thread tiles leaves CUs idle; the one-lane-per-four fold kernel has many more,
     // smaller workgroups and wins there (2^20: 15.0 vs 18.7 us, 2^21: 20.5 vs 21.2, 2^22: 36.0 vs 25.8; BH-7)
 #ifndef BHW_TILE_MIN_PW
@@ -1205,12 +1221,7 @@ int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const Bhw
         else if (mode == 1) BHW_LAUNCH_TILE_M(NB, 1);                                                                    \
         else                BHW_LAUNCH_TILE_M(NB, 2);                                                                    \
     } while (0)
-    if (nb == 15) {
-        // 64-bit sums for 15 runs do not fit the register file: bhwk_tile_applicable() routes that case to the fold kernel
-        if (mode == 2) return (int)hipErrorInvalidValue;
-        if (mode == 0) BHW_LAUNCH_TILE_M(15, 0);
-        else           BHW_LAUNCH_TILE_M(15, 1);
-    }
+    if (nb == 15) BHW_LAUNCH_TILE(15);
     else if (nb == 3) BHW_LAUNCH_TILE(3);
     else BHW_LAUNCH_TILE(1);
 #undef BHW_LAUNCH_TILE_M

@@ -268,7 +268,10 @@ TILE_CASES = [(1, 16, 16, B.MODEL_HLS, B.COMBINE_HLS), (3, 16, 24, B.MODEL_HLS, 
               (1, 22, 16, B.MODEL_CPP, B.COMBINE_HLS), (3, 22, 24, B.MODEL_HLS, B.COMBINE_VHDL),
               (5, 22, 30, B.MODEL_VHDL, B.COMBINE_VHDL), (7, 22, 12, B.MODEL_CPP, B.COMBINE_VHDL),
               (7, 22, 30, B.MODEL_HLS, B.COMBINE_HLS), (7, 23, 32, B.MODEL_CPP, B.COMBINE_HLS),
-              (7, 22, 32, B.MODEL_VHDL, B.COMBINE_HLS), (4, 22, 32, B.MODEL_HLS, B.COMBINE_HLS)]
+              (7, 22, 32, B.MODEL_VHDL, B.COMBINE_HLS), (4, 22, 32, B.MODEL_HLS, B.COMBINE_HLS),
+              # VHDL cosine-sum in the 15-run tiles (W+2-bit sum carried as 4*hi + lo), both quadrant maps, plain and packed tables
+              (7, 22, 30, B.MODEL_HLS, B.COMBINE_VHDL), (7, 22, 28, B.MODEL_CPP, B.COMBINE_VHDL),
+              (7, 22, 32, B.MODEL_VHDL, B.COMBINE_VHDL), (2, 22, 31, B.MODEL_HLS, B.COMBINE_VHDL)]
 
 
 @pytest.mark.parametrize("win,pw,w,model,combine", TILE_CASES)
@@ -280,6 +283,17 @@ def test_whole_period_tile_path(torch, win, pw, w, model, combine):
     # two periods: the second is the store-only replica of the first
     two = gpu_generate(p, n, 2 * n, B.ALGO_TABLE)
     assert np.array_equal(two[:n], want) and np.array_equal(two[n:], want)
+
+
+@pytest.mark.parametrize("combine", [B.COMBINE_HLS, B.COMBINE_VHDL])
+@pytest.mark.parametrize("win,w", [(7, 30), (5, 24), (2, 32)])
+def test_tile_path_with_wrapping_caller_weights(torch, win, w, combine):
+    """AA0..AA6 are ports: full-range random weights make the W / W+1 / W+2-bit sums of both rules wrap; tile kernels at 2^22."""
+    rng = np.random.default_rng(win * 100 + w + combine)
+    aa = [int(v) for v in rng.integers(-(1 << (w - 1)), 1 << (w - 1), 7)]
+    p = B.make_params(win, 22, w, combine=combine, aa=aa)
+    n = 1 << 22
+    assert np.array_equal(gpu_generate(p, 0, n, B.ALGO_TABLE), O.generate_mt(O.from_bhw(p), 0, n))
 
 
 def test_strategies_agree_on_random_whole_windows(torch):
