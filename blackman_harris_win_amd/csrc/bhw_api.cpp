@@ -335,14 +335,18 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
     const bool has_period = count >= (N - n0 % N) % N + N;
     const bool tiled = has_period && bhwk_tile_applicable(c, w);
     c.tab_split = (tiled && c.z_shr == 0) ? 1u : 0u;
-    // whole-period tile tables are stored packed when the widths allow it (4 bytes per entry + one int2 record per 64
-    // entries instead of 8 bytes per entry): the combine pass is bound by table + output traffic, and this halves the
-    // table's share.  Both parts live in the same scratch: [ deltas, E * 4 B | block heads at byte offset E * 4, E / 8 B ].
-    // BHW_TABLE_PACK=0 in the environment keeps the plain int2 table (A/B and equivalence tests).
-    static const bool pack = [] { const char *e = getenv("BHW_TABLE_PACK"); return !(e && e[0] == '0'); }();
-    c.tab_dlog = (tiled && pack && bhwk_packed_ok(c)) ? 6u : 0u;
+    // whole-period tile tables are stored packed when the widths allow it (formats in bhw_kernels.hip): "residual" = 2 bytes per
+    // entry + one int4 record per 2^d entries, else "delta16" = 4 bytes per entry + one int2 head per 64 entries, else the plain
+    // 8 bytes per entry.  The combine pass is bound by table + output traffic as much as by arithmetic.  Entries and records live
+    // in the same scratch: [ entries | ... | records at byte offset E * 4 ].
+    // BHW_TABLE_PACK in the environment: 0 = plain, 1 = at most delta16, unset / 2 = best (A/B and equivalence tests).
+    static const int pack = [] { const char *e = getenv("BHW_TABLE_PACK"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }();
+    c.tab_dlog = 0u;
+    if (tiled && pack >= 2) c.tab_dlog = bhwk_resid_dlog(c);
+    if (tiled && pack >= 1 && c.tab_dlog == 0u && bhwk_packed_ok(c)) c.tab_dlog = 6u;
     c.tab_coarse = c.tab_dlog ? (const void *)((const char *)ws + table_entries(c) * 4ull) : nullptr;
-    int e;
+    int e = bhwk_coarse_build(l, c);
+    if (e) return fail_hip(e, "table record launch");
     e = bhwk_table_build(l, c, (int32_t *)ws);
     if (e) return fail_hip(e, "table build launch");
     if (ex && ex->event_after_build) {

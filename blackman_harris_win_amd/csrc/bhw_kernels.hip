@@ -88,36 +88,58 @@ __device__ __forceinline__ uint32_t tab_index(uint32_t u, uint32_t log2_entries,
     return (u >> (2u - odd)) + (odd ? (e >> 1) : mid);
 }
 
-// Packed table (cfg.tab_dlog = 6, z_shr == 0 only).  (c, s)(t) is smooth in t: inside an aligned block of 64 entries it
-// moves by at most 63 * 2 pi * 2^(W-2-PW) (+ the CORDIC's rounding noise of a few LSB), which fits int16 whenever
-// W - PW <= 8 (bhwk_packed_ok).  The table then stores, per entry, the two 16-bit differences to the block's first entry
-// in one dword, and the first entries themselves as int2 records in a side array (8 bytes per 64 entries, E/8 bytes in all:
-// L2-resident).  Exact by construction -- no predictor, two adds to unpack -- and the window's table traffic, which
-// bounds the combine pass, halves.
+// Packed tables (z_shr == 0 only).  (c, s)(t) is smooth in t, so whole-period tile calls store less than 8 bytes per entry.
+// Both formats are exact by construction and keep the layout (index) of the plain table; cfg.tab_dlog selects:
+//   6      "delta16": inside an aligned block of 64 entries (c, s) moves by at most 63 * 2 pi * 2^(W-2-PW) (+ the CORDIC's
+//          rounding noise of a few LSB), which fits int16 whenever W - PW <= 8 (bhwk_packed_ok).  One dword per entry = the
+//          two 16-bit differences to the block's first entry; the first entries are int2 records at cfg.tab_coarse
+//          (8 bytes per 64 entries).  Two adds to unpack.
+//   7..9   "residual": between two exact records 2^d entries apart the curve deviates from the straight line through them by
+//          the CORDIC's own rounding noise (a few LSB: <= 32 rotations of < 1 LSB each, in x and in the residual angle) plus
+//          < 1 LSB of curvature (d is chosen for that, bhwk_resid_dlog).  Two bytes per entry = that deviation for c and s;
+//          int4 records {c, s, dc, ds} at cfg.tab_coarse (16 bytes per 2^d entries).  Build and combine evaluate the same
+//          integer predictor  rec.c + ((rec.dc * (t mod 2^d)) >> d),  so the reconstruction is exact as long as the deviation
+//          fits int8 (tests/test_oracle.py::test_residual_format_margin measures <= 40 over every model and width).
+// The combine pass is bound by table + output traffic as much as by arithmetic, and these cut the table's share to 1/2 and 1/4.
 constexpr uint32_t kPackLog = 6;
 
-// FMT: -1 format read from cfg.tab_dlog at run time, 0 plain int2 entries, 1 packed.
+__device__ __forceinline__ int2 tab_predict(const int4 rec, uint32_t f, uint32_t d)
+{
+    return make_int2(rec.x + (__mul24(rec.z, (int32_t)f) >> d), rec.y + (__mul24(rec.w, (int32_t)f) >> d));   // |dc|, |ds| < 2^17, f < 2^9
+}
+
+// FMT: -1 format read from cfg.tab_dlog at run time, 0 plain int2 entries, 1 delta16, 2 residual.
 template <int KCLASS = 0, int FMT = -1, int SPLIT = -1>
 __device__ __forceinline__ int2 tab_load(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t log2_entries)
 {
     const uint32_t idx = tab_index<KCLASS, SPLIT>(u, log2_entries, cfg.tab_split);
     if (FMT == 0 || (FMT < 0 && cfg.tab_dlog == 0)) return reinterpret_cast<const int2 *>(table)[idx];
-    const uint32_t e = reinterpret_cast<const uint32_t *>(table)[idx];
-    const int2 base = reinterpret_cast<const int2 *>(cfg.tab_coarse)[u >> kPackLog];
-    return make_int2(base.x + (int32_t)(int16_t)(e & 0xFFFFu), base.y + ((int32_t)e >> 16));
+    if (FMT == 1 || (FMT < 0 && cfg.tab_dlog == kPackLog)) {
+        const uint32_t e = reinterpret_cast<const uint32_t *>(table)[idx];
+        const int2 base = reinterpret_cast<const int2 *>(cfg.tab_coarse)[u >> kPackLog];
+        return make_int2(base.x + (int32_t)(int16_t)(e & 0xFFFFu), base.y + ((int32_t)e >> 16));
+    }
+    const uint32_t d = cfg.tab_dlog;
+    const uint32_t e = reinterpret_cast<const uint16_t *>(table)[idx];
+    const int2 p = tab_predict(reinterpret_cast<const int4 *>(cfg.tab_coarse)[u >> d], u & ((1u << d) - 1u), d);
+    return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
 }
 
-// `base` = (c, s) of the first entry of u's 64-entry block (packed format only; the caller holds it: lane 0 of the wave)
-__device__ __forceinline__ void tab_store(void *__restrict__ table, uint32_t u, uint32_t log2_entries, uint32_t split, uint32_t packed,
-                                          void *coarse, int32_t c, int32_t s, int2 base)
+// `head` = (c, s) of the first entry of u's 64-entry block (delta16; the caller holds it: lane 0 of the wave);
+// `rec` = the residual format's record of u's cell (wave-uniform: a 64-entry block lies inside one cell).
+__device__ __forceinline__ void tab_store(void *__restrict__ table, uint32_t u, uint32_t log2_entries, uint32_t split, uint32_t dlog,
+                                          void *coarse, int32_t c, int32_t s, int2 head, int4 rec)
 {
     const uint32_t idx = tab_index(u, log2_entries, split);
-    if (!packed) {
+    if (dlog == 0) {
         reinterpret_cast<int2 *>(table)[idx] = make_int2(c, s);
-        return;
+    } else if (dlog == kPackLog) {
+        reinterpret_cast<uint32_t *>(table)[idx] = ((uint32_t)(c - head.x) & 0xFFFFu) | ((uint32_t)(s - head.y) << 16);
+        if ((u & ((1u << kPackLog) - 1u)) == 0u) reinterpret_cast<int2 *>(coarse)[u >> kPackLog] = make_int2(c, s);
+    } else {
+        const int2 p = tab_predict(rec, u & ((1u << dlog) - 1u), dlog);
+        reinterpret_cast<uint16_t *>(table)[idx] = (uint16_t)(((uint32_t)(c - p.x) & 0xFFu) | (((uint32_t)(s - p.y) & 0xFFu) << 8));
     }
-    reinterpret_cast<uint32_t *>(table)[idx] = ((uint32_t)(c - base.x) & 0xFFFFu) | ((uint32_t)(s - base.y) << 16);
-    if ((u & ((1u << kPackLog) - 1u)) == 0u) reinterpret_cast<int2 *>(coarse)[u >> kPackLog] = make_int2(c, s);
 }
 
 // Accumulate one harmonic.  HLS rule: hls/windows/win_function.cpp:368-375;
@@ -220,8 +242,9 @@ __global__ __launch_bounds__(kBlock) void k_table_build(BhwCordicCfg cfg, uint32
     cordic_q1<T>(lut_s, (T)cfg.x0, (T)((T)u << cfg.z_shl), (int)cfg.n_iter, x, y);
     const int32_t c = (int32_t)(x >> cfg.out_shr), sn = (int32_t)(y >> cfg.out_shr);
     // a wave holds one aligned 64-entry block (the packed format needs entries >= 64, see bhwk_packed_ok)
-    const int2 base = make_int2(__builtin_amdgcn_readfirstlane(c), __builtin_amdgcn_readfirstlane(sn));
-    tab_store(table, u, cfg.phi_width - 2 - cfg.z_shr, cfg.tab_split, cfg.tab_dlog, const_cast<void *>(cfg.tab_coarse), c, sn, base);
+    const int2 head = make_int2(__builtin_amdgcn_readfirstlane(c), __builtin_amdgcn_readfirstlane(sn));
+    const int4 rec = cfg.tab_dlog > kPackLog ? reinterpret_cast<const int4 *>(cfg.tab_coarse)[u >> cfg.tab_dlog] : make_int4(0, 0, 0, 0);
+    tab_store(table, u, cfg.phi_width - 2 - cfg.z_shr, cfg.tab_split, cfg.tab_dlog, const_cast<void *>(cfg.tab_coarse), c, sn, head, rec);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -338,9 +361,38 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
             if (k >= k0) rot_step(x, y, z, k, plan.lut[k]);
         }
         const int32_t c = (int32_t)(x >> plan.out_shr), sn = (int32_t)(y >> plan.out_shr);
-        const int2 base = make_int2(__builtin_amdgcn_readfirstlane(c), __builtin_amdgcn_readfirstlane(sn));   // leaf 0 of the group
-        tab_store(table, (g << 6) + lane, plan.log2_entries, plan.tab_split, plan.tab_dlog, const_cast<void *>(plan.tab_coarse), c, sn, base);
+        const int2 head = make_int2(__builtin_amdgcn_readfirstlane(c), __builtin_amdgcn_readfirstlane(sn));   // leaf 0 of the group
+        const int4 rec = plan.tab_dlog > kPackLog ? reinterpret_cast<const int4 *>(plan.tab_coarse)[(g << 6) >> plan.tab_dlog]
+                                                  : make_int4(0, 0, 0, 0);                                      // wave-uniform
+        tab_store(table, (g << 6) + lane, plan.log2_entries, plan.tab_split, plan.tab_dlog, const_cast<void *>(plan.tab_coarse), c, sn, head, rec);
     }
+}
+
+// Records of the residual format: thread i evaluates the full chain (no sharing; only E >> d of them) at t = i*2^d and at the
+// next grid point with the very rot_step of the table build, and stores {c, s, dc, ds}.  The last cell has no next point inside
+// the quadrant and reuses the slope of the cell before it (its curvature error stays far inside the residual byte).
+template <int NITER>
+__global__ __launch_bounds__(kBlock) void k_coarse_build(BhwBuildPlan plan, int4 *__restrict__ coarse)
+{
+    const uint32_t d = plan.tab_dlog;
+    const uint32_t cells = plan.entries >> d;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= cells) return;
+    const bool last = (i + 1 == cells);
+    const uint32_t ua = (last ? i - 1 : i) << d, ub = ua + (1u << d);
+    int32_t cc[2], ss[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const uint32_t u = e ? ub : ua;
+        int64_t x = plan.x0, y = plan.x0;
+        int32_t z = (int32_t)((u << plan.z_shl) - plan.lut[0]);
+#pragma unroll
+        for (int r = 1; r < NITER; ++r) rot_step(x, y, z, r, plan.lut[r]);
+        cc[e] = (int32_t)(x >> plan.out_shr);
+        ss[e] = (int32_t)(y >> plan.out_shr);
+    }
+    const int32_t dc = cc[1] - cc[0], ds = ss[1] - ss[0];
+    coarse[i] = last ? make_int4(cc[1], ss[1], dc, ds) : make_int4(cc[0], ss[0], dc, ds);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -609,7 +661,7 @@ __device__ __forceinline__ void tile_accumulate(const int32_t (&sv)[4], Sum32 (&
 // Lane r in [0, E/2) owns the eight coefficients n = r + h*E/2 + j*E (h = 0,1; j = 0..3).  For even k the
 // two h-images share one gather (k*E/2 is a whole number of quadrants); for odd k the second image reads
 // entry t + E/2, another dense span of the same tile.
-template <int NB, int MODE, bool COMP>
+template <int NB, int MODE, int FMT>
 __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 4 : BHW_TILE_WAVES))) void k_table_combine_tile(BhwCordicCfg cfg, BhwWinCfg win, BhwTilePlan tp,
                                                                       const void *__restrict__ table, int32_t *__restrict__ out)
 {
@@ -653,8 +705,8 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
         _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
             _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                             \
                 const uint32_t theta = (uint32_t)K * (rr[b] + (uint32_t)g * H);                          \
-                cs[b][g] = (NB > 1) ? tab_load<KC, COMP ? 1 : 0, 1>(cfg, table, theta & emask, lq)       \
-                                    : tab_load<KC, COMP ? 1 : 0, -1>(cfg, table, (theta & emask) >> cfg.z_shr, lq - cfg.z_shr); \
+                cs[b][g] = (NB > 1) ? tab_load<KC, FMT, 1>(cfg, table, theta & emask, lq)                \
+                                    : tab_load<KC, FMT, -1>(cfg, table, (theta & emask) >> cfg.z_shr, lq - cfg.z_shr); \
             }                                                                                            \
         }                                                                                                \
         _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
@@ -1098,6 +1150,53 @@ bool bhwk_packed_ok(const BhwCordicCfg &c)
     return (int)c.dat_width - (int)c.phi_width <= 8;
 }
 
+// Residual format: largest d <= 9 for which the straight line between records 2^d entries apart stays within half an LSB of
+// the true curve: (2 pi 2^d / 2^PW)^2 / 8 * 2^(W-2) <= 0.5.  0 = not applicable (d = 6 is left to delta16).
+uint32_t bhwk_resid_dlog(const BhwCordicCfg &c)
+{
+    if (c.z_shr != 0 || c.phi_width < 20 || c.dat_width + c.out_shr > 34 || c.n_iter < 7) return 0;
+    const int amp_bits = (int)c.dat_width - 2;                       // |c|, |s| <= 2^(W-2) (+1)
+    const int twice_d = 2 * (int)c.phi_width - amp_bits - 4;         // 4.93 * 2^(2d - 2PW + W - 2) <= 0.5
+    int d = twice_d / 2;
+    if (d > 9) d = 9;
+    if (d <= (int)kPackLog) return 0;                                // a 64-leaf build group must sit inside one cell
+    if ((int)c.phi_width - 2 - d < 2) return 0;
+    return (uint32_t)d;
+}
+
+int bhwk_coarse_build(const BhwLaunch &l, const BhwCordicCfg &c)
+{
+    if (c.tab_dlog <= kPackLog) return 0;
+    BHW_SET_DEVICE(l);
+    hipStream_t st = (hipStream_t)l.stream;
+    BhwBuildPlan plan;
+    for (uint32_t k = 0; k < 32; ++k) plan.lut[k] = (uint32_t)c.lut[k];
+    plan.entries = 1u << (c.phi_width - 2 - c.z_shr);
+    plan.n_iter = c.n_iter;
+    plan.z_shl = c.z_shl;
+    plan.out_shr = c.out_shr;
+    plan.log2_entries = c.phi_width - 2 - c.z_shr;
+    plan.tab_split = c.tab_split;
+    plan.tab_dlog = c.tab_dlog;
+    plan.pad0 = 0;
+    plan.tab_coarse = c.tab_coarse;
+    plan.groups_per_wg = 64;
+    plan.pad = 0;
+    plan.x0 = c.x0;
+    const uint32_t cells = plan.entries >> c.tab_dlog;
+    const dim3 grid(grid_for(cells)), block(kBlock);
+    switch (c.n_iter) {
+#define BHW_CASE(N) case N: hipLaunchKernelGGL(k_coarse_build<N>, grid, block, 0, st, plan, (int4 *)const_cast<void *>(c.tab_coarse)); break;
+        BHW_CASE(7) BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14)
+        BHW_CASE(15) BHW_CASE(16) BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20) BHW_CASE(21) BHW_CASE(22)
+        BHW_CASE(23) BHW_CASE(24) BHW_CASE(25) BHW_CASE(26) BHW_CASE(27) BHW_CASE(28) BHW_CASE(29) BHW_CASE(30)
+        BHW_CASE(31) BHW_CASE(32)
+#undef BHW_CASE
+    default: return (int)hipErrorInvalidValue;
+    }
+    return finish(hipSuccess);
+}
+
 int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table)
 {
     BHW_SET_DEVICE(l);
@@ -1212,8 +1311,9 @@ int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const Bhw
     const dim3 grid(tp.n_tiles), block(kTileThreads);
 #define BHW_LAUNCH_TILE_M(NB, M)                                                                                         \
     do {                                                                                                                 \
-        if (c.tab_dlog) hipLaunchKernelGGL((k_table_combine_tile<NB, M, true>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
-        else            hipLaunchKernelGGL((k_table_combine_tile<NB, M, false>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
+        if (c.tab_dlog == 0)             hipLaunchKernelGGL((k_table_combine_tile<NB, M, 0>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
+        else if (c.tab_dlog == kPackLog) hipLaunchKernelGGL((k_table_combine_tile<NB, M, 1>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
+        else                             hipLaunchKernelGGL((k_table_combine_tile<NB, M, 2>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
     } while (0)
 #define BHW_LAUNCH_TILE(NB)                                                                                              \
     do {                                                                                                                 \

@@ -506,23 +506,23 @@ def test_c3_full_64m(torch, golden):
 
 
 def test_packed_table_is_exact(torch, golden):
-    """The packed table (int16 differences to the first entry of each 64-entry block; default where W - PW <= 8) must give the
-    same coefficients as the plain int2 table (BHW_TABLE_PACK=0)."""
+    """The packed tables -- "residual" (2 bytes per entry against a linear predictor) and "delta16" (int16 differences to the first
+    entry of each 64-entry block) -- must give the same coefficients as the plain int2 table (BHW_TABLE_PACK = 2 / 1 / 0)."""
     import subprocess, sys
     code = (
         "import hashlib, sys; sys.path.insert(0, %r)\n"
         "import blackman_harris_win_amd as bhw\n"
         "from blackman_harris_win_amd import binding as B\n"
-        "for win, pw, w, model in ((7, 26, 32, 0), (7, 24, 32, 1), (4, 22, 24, 2), (5, 23, 29, 0), (7, 22, 28, 2), (3, 22, 30, 0)):\n"
+        "for win, pw, w, model in ((7, 26, 32, 0), (7, 24, 32, 1), (4, 22, 24, 2), (5, 23, 29, 0), (7, 22, 28, 2), (3, 22, 30, 0), (7, 22, 32, 0), (7, 25, 26, 1)):\n"
         "    p = B.make_params(win, pw, w, model=model)\n"
         "    a = bhw.generate(p, 12345, (1 << pw) + 99999, algo=B.ALGO_TABLE).cpu().numpy()\n"
         "    print(hashlib.md5(a.tobytes()).hexdigest())\n" % ROOT)
     outs = []
-    for flag in ("0", "1"):
+    for flag in ("0", "1", "2"):
         env = dict(os.environ, BHW_TABLE_PACK=flag)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, check=True)
         outs.append(r.stdout.split())
-    assert outs[0] == outs[1] and len(outs[0]) == 6
+    assert outs[0] == outs[1] == outs[2] and len(outs[0]) == 8
 
 
 def test_c3_full_64m_model_cpp(torch, golden):

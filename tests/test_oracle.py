@@ -314,6 +314,34 @@ def test_typed_store_wraps_never_fire():
     assert ev.value == 0
 
 
+def test_residual_format_margin():
+    """The 2-byte "residual" table format (bhw_kernels.hip) stores (c, s) minus a straight line through exact records 2^d
+    entries apart in one signed byte per component.  Measure that deviation over every model, at the widths the format is used
+    for (d from the same rule as bhwk_resid_dlog): it must stay far inside int8."""
+    rng = np.random.default_rng(17)
+    worst = 0
+    for model, prec, out_shr in [(O.MODEL_HLS, 1, 2), (O.MODEL_CPP, 1, 2), (O.MODEL_VHDL, 1, 1), (O.MODEL_VHDL, 2, 2)]:
+        for pw, w in [(26, 32), (24, 32), (22, 30), (22, 24), (20, 24), (26, 26), (23, 31), (28, 32), (30, 32), (21, 27)]:
+            if model == O.MODEL_HLS and pw > w + 2:
+                continue
+            if pw >= w or w + out_shr > 34:                       # phase bits dropped / 64-bit build: plain table
+                continue
+            d = min(9, (2 * pw - (w - 2) - 4) // 2)
+            if d <= 6:
+                continue
+            E = 1 << (pw - 2)
+            p = O.oparams(1, pw, w, model=model, precision=prec)
+            cells = np.unique(np.concatenate([[0, 1, (E >> d) - 2, (E >> d) // 2], rng.integers(0, (E >> d) - 1, 3)]))
+            for cell in cells:
+                u0 = int(cell) << d
+                s, c = O.sincos(p, u0, (1 << d) + 1)
+                f = np.arange(1 << d, dtype=np.int64)
+                pc = c[0] + (((int(c[-1]) - int(c[0])) * f) >> d)
+                ps = s[0] + (((int(s[-1]) - int(s[0])) * f) >> d)
+                worst = max(worst, int(np.abs(c[:-1] - pc).max()), int(np.abs(s[:-1] - ps).max()))
+    assert 0 < worst <= 40, worst
+
+
 def test_quadrant_images_share_first_quadrant_result():
     """cos/sin at theta + j*N/4 are the quadrant-rotated first-quadrant pair (basis of the table strategy)."""
     for model in (O.MODEL_HLS, O.MODEL_CPP, O.MODEL_VHDL):
