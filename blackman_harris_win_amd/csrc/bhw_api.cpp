@@ -345,9 +345,7 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
     if (tiled && pack >= 2) c.tab_dlog = bhwk_resid_dlog(c);
     if (tiled && pack >= 1 && c.tab_dlog == 0u && bhwk_packed_ok(c)) c.tab_dlog = 6u;
     c.tab_coarse = c.tab_dlog ? (const void *)((const char *)ws + table_entries(c) * 4ull) : nullptr;
-    int e = bhwk_coarse_build(l, c);
-    if (e) return fail_hip(e, "table record launch");
-    e = bhwk_table_build(l, c, (int32_t *)ws);
+    int e = bhwk_table_build(l, c, (int32_t *)ws);
     if (e) return fail_hip(e, "table build launch");
     if (ex && ex->event_after_build) {
         hipError_t he = hipEventRecord((hipEvent_t)ex->event_after_build, (hipStream_t)stream);

@@ -79,7 +79,6 @@ int bhwk_table_combine(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCf
 // coarse records for the residual-compressed table (cfg.tab_dlog > 0): int4 {c, s, dc, ds} per 2^tab_dlog entries
 bool bhwk_packed_ok(const BhwCordicCfg &c);
 uint32_t bhwk_resid_dlog(const BhwCordicCfg &c);
-int bhwk_coarse_build(const BhwLaunch &l, const BhwCordicCfg &c);
 // whole period [0, 2^PW) via the quadrant fold (one lane per four coefficients)
 int bhwk_table_combine_fold(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out);
 // whole period, 15-block super-tiles over the residue-split table (z_shr == 0 only)

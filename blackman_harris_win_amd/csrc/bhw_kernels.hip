@@ -266,6 +266,7 @@ __global__ __launch_bounds__(kBlock) void k_table_build(BhwCordicCfg cfg, uint32
 constexpr int kPrefixMax = 20;      // deepest rotation a 64-leaf group is followed to in phase 1
 constexpr int kGroupsPerWg = 64;    // phase 1: at most one group per lane of the first wave (plan.groups_per_wg <= 64)
 constexpr int kBuildThreads = 256;  // phase 2: four waves, 16 groups each
+constexpr int kHeadsMax = 40;       // residual format: cells of one workgroup (4096 entries >> 7 = 32) + 2
 
 struct BhwBuildPlan {
     uint32_t lut[32];    // the rescaled ROM as 32-bit words (entries fit: quarter circle <= 2^32)
@@ -318,6 +319,33 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
     const uint32_t group0 = blockIdx.x * gpw;
     const uint32_t n_groups = plan.entries >> 6;
 
+    // Residual format: the records {c, s, dc, ds} of the cells this workgroup touches.  Lanes of the second wave run the full
+    // chain (the very rot_step of the leaves) at the cell starts -- heads cell_lo .. cell_lo + n_cell, plus head cell_lo - 1
+    // for the table's last cell, whose end point is not an entry and which reuses the slope of the cell before it -- while
+    // the first wave runs the group prefixes; cells that start inside this workgroup are also written out for the combine pass.
+    __shared__ int32_t hc[kHeadsMax], hs[kHeadsMax];
+    const uint32_t d = plan.tab_dlog;
+    const bool resid = d > kPackLog;
+    const uint32_t cells_total = resid ? plan.entries >> d : 0u;
+    uint32_t cell_lo = 0, n_cell = 0;
+    if (resid) {
+        const uint32_t u_end = ((group0 + gpw) << 6) < plan.entries ? ((group0 + gpw) << 6) : plan.entries;
+        cell_lo = (group0 << 6) >> d;
+        n_cell = ((u_end - 1u) >> d) - cell_lo + 1u;
+    }
+    if (resid && threadIdx.x >= 64u && threadIdx.x < 64u + n_cell + 2u) {
+        const uint32_t t = threadIdx.x - 64u;
+        const int64_t cell = (t <= n_cell) ? (int64_t)cell_lo + t : (int64_t)cell_lo - 1;
+        if (cell >= 0 && cell < (int64_t)cells_total) {
+            int64_t x = plan.x0, y = plan.x0;
+            int32_t z = (int32_t)((((uint32_t)cell << d) << s) - lut_s[0]);
+#pragma unroll 1
+            for (int r = 1; r < n_iter; ++r) rot_step(x, y, z, r, lut_s[r]);
+            hc[t] = (int32_t)(x >> plan.out_shr);
+            hs[t] = (int32_t)(y >> plan.out_shr);
+        }
+    }
+
     // ---- phase 1: shared prefix of each 64-leaf group ----
     if (threadIdx.x < gpw) {
         const uint32_t g = group0 + threadIdx.x;
@@ -346,6 +374,18 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
     }
     __syncthreads();
 
+    auto record = [&](uint32_t cell) -> int4 {                     // cell in [cell_lo, cell_lo + n_cell)
+        const uint32_t t = cell - cell_lo;
+        if (cell + 1u < cells_total) return make_int4(hc[t], hs[t], hc[t + 1] - hc[t], hs[t + 1] - hs[t]);
+        const uint32_t tp = t ? t - 1u : n_cell + 1u;                // last cell of the table: slope of the cell before it
+        return make_int4(hc[t], hs[t], hc[t] - hc[tp], hs[t] - hs[tp]);
+    };
+    if (resid && threadIdx.x < n_cell) {
+        const uint32_t cell = cell_lo + threadIdx.x;
+        if ((cell << d) >= (group0 << 6))                            // starts inside this workgroup's entries: this one writes it
+            reinterpret_cast<int4 *>(const_cast<void *>(plan.tab_coarse))[cell] = record(cell);
+    }
+
     // ---- phase 2: one wave per group, one lane per leaf, remaining rotations only ----
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (uint32_t gi = wave; gi < gpw; gi += kBuildThreads / 64) {
@@ -362,37 +402,9 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
         }
         const int32_t c = (int32_t)(x >> plan.out_shr), sn = (int32_t)(y >> plan.out_shr);
         const int2 head = make_int2(__builtin_amdgcn_readfirstlane(c), __builtin_amdgcn_readfirstlane(sn));   // leaf 0 of the group
-        const int4 rec = plan.tab_dlog > kPackLog ? reinterpret_cast<const int4 *>(plan.tab_coarse)[(g << 6) >> plan.tab_dlog]
-                                                  : make_int4(0, 0, 0, 0);                                      // wave-uniform
+        const int4 rec = resid ? record((g << 6) >> d) : make_int4(0, 0, 0, 0);                                // wave-uniform
         tab_store(table, (g << 6) + lane, plan.log2_entries, plan.tab_split, plan.tab_dlog, const_cast<void *>(plan.tab_coarse), c, sn, head, rec);
     }
-}
-
-// Records of the residual format: thread i evaluates the full chain (no sharing; only E >> d of them) at t = i*2^d and at the
-// next grid point with the very rot_step of the table build, and stores {c, s, dc, ds}.  The last cell has no next point inside
-// the quadrant and reuses the slope of the cell before it (its curvature error stays far inside the residual byte).
-template <int NITER>
-__global__ __launch_bounds__(kBlock) void k_coarse_build(BhwBuildPlan plan, int4 *__restrict__ coarse)
-{
-    const uint32_t d = plan.tab_dlog;
-    const uint32_t cells = plan.entries >> d;
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= cells) return;
-    const bool last = (i + 1 == cells);
-    const uint32_t ua = (last ? i - 1 : i) << d, ub = ua + (1u << d);
-    int32_t cc[2], ss[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const uint32_t u = e ? ub : ua;
-        int64_t x = plan.x0, y = plan.x0;
-        int32_t z = (int32_t)((u << plan.z_shl) - plan.lut[0]);
-#pragma unroll
-        for (int r = 1; r < NITER; ++r) rot_step(x, y, z, r, plan.lut[r]);
-        cc[e] = (int32_t)(x >> plan.out_shr);
-        ss[e] = (int32_t)(y >> plan.out_shr);
-    }
-    const int32_t dc = cc[1] - cc[0], ds = ss[1] - ss[0];
-    coarse[i] = last ? make_int4(cc[1], ss[1], dc, ds) : make_int4(cc[0], ss[0], dc, ds);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1164,39 +1176,6 @@ uint32_t bhwk_resid_dlog(const BhwCordicCfg &c)
     return (uint32_t)d;
 }
 
-int bhwk_coarse_build(const BhwLaunch &l, const BhwCordicCfg &c)
-{
-    if (c.tab_dlog <= kPackLog) return 0;
-    BHW_SET_DEVICE(l);
-    hipStream_t st = (hipStream_t)l.stream;
-    BhwBuildPlan plan;
-    for (uint32_t k = 0; k < 32; ++k) plan.lut[k] = (uint32_t)c.lut[k];
-    plan.entries = 1u << (c.phi_width - 2 - c.z_shr);
-    plan.n_iter = c.n_iter;
-    plan.z_shl = c.z_shl;
-    plan.out_shr = c.out_shr;
-    plan.log2_entries = c.phi_width - 2 - c.z_shr;
-    plan.tab_split = c.tab_split;
-    plan.tab_dlog = c.tab_dlog;
-    plan.pad0 = 0;
-    plan.tab_coarse = c.tab_coarse;
-    plan.groups_per_wg = 64;
-    plan.pad = 0;
-    plan.x0 = c.x0;
-    const uint32_t cells = plan.entries >> c.tab_dlog;
-    const dim3 grid(grid_for(cells)), block(kBlock);
-    switch (c.n_iter) {
-#define BHW_CASE(N) case N: hipLaunchKernelGGL(k_coarse_build<N>, grid, block, 0, st, plan, (int4 *)const_cast<void *>(c.tab_coarse)); break;
-        BHW_CASE(7) BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14)
-        BHW_CASE(15) BHW_CASE(16) BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20) BHW_CASE(21) BHW_CASE(22)
-        BHW_CASE(23) BHW_CASE(24) BHW_CASE(25) BHW_CASE(26) BHW_CASE(27) BHW_CASE(28) BHW_CASE(29) BHW_CASE(30)
-        BHW_CASE(31) BHW_CASE(32)
-#undef BHW_CASE
-    default: return (int)hipErrorInvalidValue;
-    }
-    return finish(hipSuccess);
-}
-
 int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table)
 {
     BHW_SET_DEVICE(l);
@@ -1232,6 +1211,7 @@ int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table
         }
         return finish(hipSuccess);
     }
+    if (c.tab_dlog > kPackLog) return (int)hipErrorInvalidValue;        // residual records come from the shared-prefix kernel only
     if (c.wide) hipLaunchKernelGGL(k_table_build<int64_t>, dim3(grid_for(entries)), dim3(kBlock), 0, st, c, entries, (void *)d_table);
     else        hipLaunchKernelGGL(k_table_build<int32_t>, dim3(grid_for(entries)), dim3(kBlock), 0, st, c, entries, (void *)d_table);
     return finish(hipSuccess);
