@@ -1415,28 +1415,33 @@ __global__ __launch_bounds__(kBlock) void k_sincos_prerot(BhwPrerotCfg c, uint64
     if (d_cos) d_cos[i] = (int32_t)(x >> (c.size - NITER));
 }
 
-// cordic_atan2 (src/cordic_atan2.vhd:126-213)
+// cordic_atan2 (src/cordic_atan2.vhd:126-213).  The B = ANGLE_WIDTH + PRECISION bit registers do wrap (PRECISION 1 with
+// full-scale inputs), so the state is kept shifted left by 64 - B: 64-bit overflow then *is* the B-bit wrap, and the only
+// extra work is clearing the 64 - B low bits that an arithmetic right shift drags in.
 __global__ __launch_bounds__(kBlock) void k_atan2(BhwAtan2Cfg c, uint64_t count, const int32_t *__restrict__ d_x,
                                                    const int32_t *__restrict__ d_y, int32_t *__restrict__ d_phi)
 {
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= count) return;
-    const uint32_t IW = c.input_width, AW = c.angle_width, B = AW + c.precision;
-    const uint64_t im = (IW >= 64) ? ~0ull : ((1ull << IW) - 1ull);
+    const uint32_t IW = c.input_width, AW = c.angle_width, B = AW + c.precision, sh = 64u - B;
+    const uint64_t im = (1ull << IW) - 1ull;                             // IW <= 32
     const uint64_t ux = (uint64_t)(int64_t)d_x[i] & im, uy = (uint64_t)(int64_t)d_y[i] & im;
     const uint32_t sx = (uint32_t)(ux >> (IW - 1)) & 1u, sy = (uint32_t)(uy >> (IW - 1)) & 1u;
     const uint64_t lowm = (1ull << (AW - 1)) - 1ull;
-    int64_t x = (int64_t)((sx ? ~ux : ux) & lowm);                       // :142-147
-    int64_t y = (int64_t)((sy ? ~uy : uy) & lowm);
-    int64_t z = 0;                                                      // :152
+    const uint64_t keep = ~((1ull << sh) - 1ull);
+    uint64_t X = ((sx ? ~ux : ux) & lowm) << sh;                         // :142-147
+    uint64_t Y = ((sy ? ~uy : uy) & lowm) << sh;
+    uint64_t Z = 0;                                                     // :152
     for (uint32_t ii = 0; ii + 1 < AW; ++ii) {                          // :172-190
-        const int64_t xs = x >> ii, ys = y >> ii;
-        const bool pos = y >= 0;
-        x = wrap_bits(pos ? x + ys : x - ys, B);
-        y = wrap_bits(pos ? y - xs : y + xs, B);
-        z = wrap_bits(pos ? z - c.lut[ii] : z + c.lut[ii], B);
+        const uint64_t xs = (uint64_t)((int64_t)X >> ii) & keep, ys = (uint64_t)((int64_t)Y >> ii) & keep;
+        const uint64_t rom = (uint64_t)c.lut[ii] << sh;
+        const bool pos = (int64_t)Y >= 0;
+        X = pos ? X + ys : X - ys;
+        Y = pos ? Y - xs : Y + xs;
+        Z = pos ? Z - rom : Z + rom;
     }
-    const int64_t phi = wrap_bits(z >> c.precision, AW);                // :194
+    // :194  sigZ(ANGLE_WIDTH-1)(B-1 downto PRECISION): the top ANGLE_WIDTH bits of the B-bit word
+    const int64_t phi = (int64_t)Z >> (64u - AW);
     const int64_t pi_word = (int64_t)1 << (AW - 2);                     // PHI_PI :112
     const uint32_t quad = (sx << 1) | sy;                               // :126-128
     const int64_t out = quad == 0u ? phi : quad == 1u ? phi + pi_word : quad == 2u ? -phi : phi - pi_word;   // :207-213
