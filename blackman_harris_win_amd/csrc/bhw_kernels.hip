@@ -127,13 +127,14 @@ __device__ __forceinline__ int2 tab_load(const BhwCordicCfg &cfg, const void *__
 
 // `head` = (c, s) of the first entry of u's 64-entry block (delta16; the caller holds it: lane 0 of the wave);
 // `rec` = the residual format's record of u's cell (wave-uniform: a 64-entry block lies inside one cell).
+template <int FMT = -1>
 __device__ __forceinline__ void tab_store(void *__restrict__ table, uint32_t u, uint32_t log2_entries, uint32_t split, uint32_t dlog,
                                           void *coarse, int32_t c, int32_t s, int2 head, int4 rec)
 {
     const uint32_t idx = tab_index(u, log2_entries, split);
-    if (dlog == 0) {
+    if (FMT == 0 || (FMT < 0 && dlog == 0)) {
         reinterpret_cast<int2 *>(table)[idx] = make_int2(c, s);
-    } else if (dlog == kPackLog) {
+    } else if (FMT == 1 || (FMT < 0 && dlog == kPackLog)) {
         reinterpret_cast<uint32_t *>(table)[idx] = ((uint32_t)(c - head.x) & 0xFFFFu) | ((uint32_t)(s - head.y) << 16);
         if ((u & ((1u << kPackLog) - 1u)) == 0u) reinterpret_cast<int2 *>(coarse)[u >> kPackLog] = make_int2(c, s);
     } else {
@@ -302,7 +303,8 @@ __device__ __forceinline__ void rot_step(int64_t &x, int64_t &y, int32_t &z, int
     else                 z = (int32_t)((uint32_t)z - lutk + ((2u * lutk) & (uint32_t)m));
 }
 
-template <int NITER>
+// FMT: table format as a template parameter (0 plain, 1 delta16, 2 residual): no format branches around the stores.
+template <int NITER, int FMT>
 __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPlan plan, void *__restrict__ table)
 {
     __shared__ int64_t gx[kGroupsPerWg];
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
     // the first wave runs the group prefixes; cells that start inside this workgroup are also written out for the combine pass.
     __shared__ int32_t hc[kHeadsMax], hs[kHeadsMax];
     const uint32_t d = plan.tab_dlog;
-    const bool resid = d > kPackLog;
+    constexpr bool resid = (FMT == 2);
     const uint32_t cells_total = resid ? plan.entries >> d : 0u;
     uint32_t cell_lo = 0, n_cell = 0;
     if (resid) {
@@ -374,16 +376,19 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
     }
     __syncthreads();
 
-    auto record = [&](uint32_t cell) -> int4 {                     // cell in [cell_lo, cell_lo + n_cell)
+    auto record_of = [&](uint32_t cell) -> int4 {                  // cell in [cell_lo, cell_lo + n_cell)
         const uint32_t t = cell - cell_lo;
         if (cell + 1u < cells_total) return make_int4(hc[t], hs[t], hc[t + 1] - hc[t], hs[t + 1] - hs[t]);
         const uint32_t tp = t ? t - 1u : n_cell + 1u;                // last cell of the table: slope of the cell before it
         return make_int4(hc[t], hs[t], hc[t] - hc[tp], hs[t] - hs[tp]);
     };
+    auto record = [&](uint32_t cell) -> int4 {                     // the same for a wave-uniform cell: scalar control flow
+        return record_of(__builtin_amdgcn_readfirstlane(cell));
+    };
     if (resid && threadIdx.x < n_cell) {
         const uint32_t cell = cell_lo + threadIdx.x;
         if ((cell << d) >= (group0 << 6))                            // starts inside this workgroup's entries: this one writes it
-            reinterpret_cast<int4 *>(const_cast<void *>(plan.tab_coarse))[cell] = record(cell);
+            reinterpret_cast<int4 *>(const_cast<void *>(plan.tab_coarse))[cell] = record_of(cell);
     }
 
     // ---- phase 2: one wave per group, one lane per leaf, remaining rotations only ----
@@ -403,7 +408,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
         const int32_t c = (int32_t)(x >> plan.out_shr), sn = (int32_t)(y >> plan.out_shr);
         const int2 head = make_int2(__builtin_amdgcn_readfirstlane(c), __builtin_amdgcn_readfirstlane(sn));   // leaf 0 of the group
         const int4 rec = resid ? record((g << 6) >> d) : make_int4(0, 0, 0, 0);                                // wave-uniform
-        tab_store(table, (g << 6) + lane, plan.log2_entries, plan.tab_split, plan.tab_dlog, const_cast<void *>(plan.tab_coarse), c, sn, head, rec);
+        tab_store<FMT>(table, (g << 6) + lane, plan.log2_entries, plan.tab_split, plan.tab_dlog, const_cast<void *>(plan.tab_coarse), c, sn, head, rec);
     }
 }
 
@@ -1200,15 +1205,23 @@ int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table
         plan.groups_per_wg = groups >= 64u * 1024u ? 64u : groups >= 16u * 1024u ? 16u : 4u;
         plan.pad = 0;
         const dim3 grid((groups + plan.groups_per_wg - 1) / plan.groups_per_wg), block(kBuildThreads);
+        // plain tables for every rotation count; the packed formats (whole-period tile calls at z_shr == 0, i.e. PW >= 22 and
+        // therefore at least 22 rotations) from 22 rotations on
+        const int fmt = c.tab_dlog == 0 ? 0 : c.tab_dlog == kPackLog ? 1 : 2;
+        if (c.n_iter < 22 && fmt != 0) return (int)hipErrorInvalidValue;
+#define BHW_LAUNCH_BUILD(N, F) hipLaunchKernelGGL((k_table_build_shared<N, F>), grid, block, 0, st, plan, (void *)d_table)
+#define BHW_CASE(N) case N: BHW_LAUNCH_BUILD(N, 0); break;
+#define BHW_CASE_T(N) case N: if (fmt == 0) BHW_LAUNCH_BUILD(N, 0); else if (fmt == 1) BHW_LAUNCH_BUILD(N, 1); else BHW_LAUNCH_BUILD(N, 2); break;
         switch (c.n_iter) {
-#define BHW_CASE(N) case N: hipLaunchKernelGGL(k_table_build_shared<N>, grid, block, 0, st, plan, (void *)d_table); break;
             BHW_CASE(7) BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14)
-            BHW_CASE(15) BHW_CASE(16) BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20) BHW_CASE(21) BHW_CASE(22)
-            BHW_CASE(23) BHW_CASE(24) BHW_CASE(25) BHW_CASE(26) BHW_CASE(27) BHW_CASE(28) BHW_CASE(29) BHW_CASE(30)
-            BHW_CASE(31) BHW_CASE(32)
-#undef BHW_CASE
+            BHW_CASE(15) BHW_CASE(16) BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20) BHW_CASE(21)
+            BHW_CASE_T(22) BHW_CASE_T(23) BHW_CASE_T(24) BHW_CASE_T(25) BHW_CASE_T(26) BHW_CASE_T(27) BHW_CASE_T(28)
+            BHW_CASE_T(29) BHW_CASE_T(30) BHW_CASE_T(31) BHW_CASE_T(32)
         default: return (int)hipErrorInvalidValue;
         }
+#undef BHW_CASE
+#undef BHW_CASE_T
+#undef BHW_LAUNCH_BUILD
         return finish(hipSuccess);
     }
     if (c.tab_dlog > kPackLog) return (int)hipErrorInvalidValue;        // residual records come from the shared-prefix kernel only
