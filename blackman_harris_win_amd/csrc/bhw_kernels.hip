@@ -393,6 +393,15 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
 
     // ---- phase 2: one wave per group, one lane per leaf, remaining rotations only ----
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    // table index of leaf (g, lane) = idx_a + g * idx_m: natural layout 64 g + lane; split layout per residue class of the lane
+    // (64 g + lane has the lane's residue mod 4), tab_index() folded into two per-lane constants
+    uint32_t idx_a = lane, idx_m = 64u;
+    if (plan.tab_split) {
+        const uint32_t e = 1u << plan.log2_entries;
+        if (lane & 1u)      { idx_a = (e >> 1) + (lane >> 1); idx_m = 32u; }
+        else if (lane & 2u) { idx_a = (e >> 2) + (lane >> 2); idx_m = 16u; }
+        else                { idx_a = lane >> 2;              idx_m = 16u; }
+    }
     for (uint32_t gi = wave; gi < gpw; gi += kBuildThreads / 64) {
         const uint32_t g = group0 + gi;
         if (g >= n_groups) break;
@@ -407,8 +416,17 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
         }
         const int32_t c = (int32_t)(x >> plan.out_shr), sn = (int32_t)(y >> plan.out_shr);
         const int2 head = make_int2(__builtin_amdgcn_readfirstlane(c), __builtin_amdgcn_readfirstlane(sn));   // leaf 0 of the group
-        const int4 rec = resid ? record((g << 6) >> d) : make_int4(0, 0, 0, 0);                                // wave-uniform
-        tab_store<FMT>(table, (g << 6) + lane, plan.log2_entries, plan.tab_split, plan.tab_dlog, const_cast<void *>(plan.tab_coarse), c, sn, head, rec);
+        const uint32_t idx = idx_a + g * idx_m;
+        if constexpr (FMT == 0) {
+            reinterpret_cast<int2 *>(table)[idx] = make_int2(c, sn);
+        } else if constexpr (FMT == 1) {
+            reinterpret_cast<uint32_t *>(table)[idx] = ((uint32_t)(c - head.x) & 0xFFFFu) | ((uint32_t)(sn - head.y) << 16);
+            if (lane == 0u) reinterpret_cast<int2 *>(const_cast<void *>(plan.tab_coarse))[g] = head;   // block = group
+        } else {
+            const int4 rec = record((g << 6) >> d);                                                     // wave-uniform
+            const int2 p = tab_predict(rec, ((g << 6) & ((1u << d) - 1u)) + lane, d);
+            reinterpret_cast<uint16_t *>(table)[idx] = (uint16_t)(((uint32_t)(c - p.x) & 0xFFu) | (((uint32_t)(sn - p.y) & 0xFFu) << 8));
+        }
     }
 }
 
