@@ -344,6 +344,7 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
     c.tab_dlog = 0u;
     if (tiled && pack >= 2) c.tab_dlog = bhwk_resid_dlog(c);
     if (tiled && pack >= 1 && c.tab_dlog == 0u && bhwk_packed_ok(c)) c.tab_dlog = 6u;
+    if (c.n_iter < 21) c.tab_dlog = 0u;                     // the packed build variants exist from 21 rotations on (always true at PW >= 22)
     c.tab_coarse = c.tab_dlog ? (const void *)((const char *)ws + table_entries(c) * 4ull) : nullptr;
     int e = bhwk_table_build(l, c, (int32_t *)ws);
     if (e) return fail_hip(e, "table build launch");

@@ -1224,16 +1224,16 @@ int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table
         plan.pad = 0;
         const dim3 grid((groups + plan.groups_per_wg - 1) / plan.groups_per_wg), block(kBuildThreads);
         // plain tables for every rotation count; the packed formats (whole-period tile calls at z_shr == 0, i.e. PW >= 22 and
-        // therefore at least 22 rotations) from 22 rotations on
+        // therefore at least 21 rotations: the VHDL model at PW == W runs W - 1 of them) from 21 rotations on
         const int fmt = c.tab_dlog == 0 ? 0 : c.tab_dlog == kPackLog ? 1 : 2;
-        if (c.n_iter < 22 && fmt != 0) return (int)hipErrorInvalidValue;
+        if (c.n_iter < 21 && fmt != 0) return (int)hipErrorInvalidValue;
 #define BHW_LAUNCH_BUILD(N, F) hipLaunchKernelGGL((k_table_build_shared<N, F>), grid, block, 0, st, plan, (void *)d_table)
 #define BHW_CASE(N) case N: BHW_LAUNCH_BUILD(N, 0); break;
 #define BHW_CASE_T(N) case N: if (fmt == 0) BHW_LAUNCH_BUILD(N, 0); else if (fmt == 1) BHW_LAUNCH_BUILD(N, 1); else BHW_LAUNCH_BUILD(N, 2); break;
         switch (c.n_iter) {
             BHW_CASE(7) BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14)
-            BHW_CASE(15) BHW_CASE(16) BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20) BHW_CASE(21)
-            BHW_CASE_T(22) BHW_CASE_T(23) BHW_CASE_T(24) BHW_CASE_T(25) BHW_CASE_T(26) BHW_CASE_T(27) BHW_CASE_T(28)
+            BHW_CASE(15) BHW_CASE(16) BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20)
+            BHW_CASE_T(21) BHW_CASE_T(22) BHW_CASE_T(23) BHW_CASE_T(24) BHW_CASE_T(25) BHW_CASE_T(26) BHW_CASE_T(27) BHW_CASE_T(28)
             BHW_CASE_T(29) BHW_CASE_T(30) BHW_CASE_T(31) BHW_CASE_T(32)
         default: return (int)hipErrorInvalidValue;
         }

@@ -271,7 +271,9 @@ TILE_CASES = [(1, 16, 16, B.MODEL_HLS, B.COMBINE_HLS), (3, 16, 24, B.MODEL_HLS, 
               (7, 22, 32, B.MODEL_VHDL, B.COMBINE_HLS), (4, 22, 32, B.MODEL_HLS, B.COMBINE_HLS),
               # VHDL cosine-sum in the 15-run tiles (W+2-bit sum carried as 4*hi + lo), both quadrant maps, plain and packed tables
               (7, 22, 30, B.MODEL_HLS, B.COMBINE_VHDL), (7, 22, 28, B.MODEL_CPP, B.COMBINE_VHDL),
-              (7, 22, 32, B.MODEL_VHDL, B.COMBINE_VHDL), (2, 22, 31, B.MODEL_HLS, B.COMBINE_VHDL)]
+              (7, 22, 32, B.MODEL_VHDL, B.COMBINE_VHDL), (2, 22, 31, B.MODEL_HLS, B.COMBINE_VHDL),
+              # fewest rotations a packed table can meet: VHDL model at PW == W (z_shr = 0, W - 1 = 21 rotations; found by the fuzzer)
+              (2, 22, 22, B.MODEL_VHDL, B.COMBINE_VHDL), (7, 22, 22, B.MODEL_HLS, B.COMBINE_HLS)]
 
 
 @pytest.mark.parametrize("win,pw,w,model,combine", TILE_CASES)

@@ -56,7 +56,8 @@ while time.time() - t0 < budget:
     win = int(rng.choice([1, 2, 3, 4, 5, 7])); K = O.TERMS[win]
     taylor = rng.random() < 0.25
     model = int(rng.integers(0, 3)); combine = int(rng.integers(0, 2))
-    w = int(rng.integers(8, 33)); pw = int(rng.integers(4, 25))
+    w = int(rng.integers(8, 33)); pw = int(rng.integers(4, 26))
+    if rng.random() < 0.15: pw = int(rng.integers(22, 26))                  # whole-period tile calls: packed table formats
     prec = int(rng.integers(1, 4)) if model == B.MODEL_VHDL else 1
     lut = 9
     if taylor:
@@ -77,10 +78,14 @@ while time.time() - t0 < budget:
     if mode < 0.35:   n0, count = 0, n                                   # whole period
     elif mode < 0.5:  n0, count = n * int(rng.integers(0, 3)), n * int(rng.integers(1, 3))
     else:             n0, count = int(rng.integers(0, 4 * n)), int(rng.integers(1, min(4 * n, 300000) + 1))
-    count = min(count, (1 << 17) if taylor else (1 << 22))          # the Taylor oracle evaluates its ROM in binary128 per sample
+    count = min(count, (1 << 17) if taylor else (1 << 25))          # the Taylor oracle evaluates its ROM in binary128 per sample
     if taylor and count < n <= (1 << 17) and mode < 0.5: n0, count = 0, n
     algo = int(rng.choice([B.ALGO_AUTO, B.ALGO_DIRECT, B.ALGO_TABLE]))
-    got = bhw.generate(p, n0, count, algo=algo).cpu().numpy()
+    try:
+        got = bhw.generate(p, n0, count, algo=algo).cpu().numpy()
+    except B.BhwError:
+        print("ERROR", dict(win=win, pw=pw, w=w, model=model, combine=combine, prec=prec, aa=aa, taylor=taylor, lut=lut, n0=n0, count=count, algo=algo), flush=True)
+        raise
     want = oracle_gen(O.from_bhw(p), n0, count)
     if not np.array_equal(got, want):
         bad = int(np.flatnonzero(got != want)[0])
