@@ -377,6 +377,26 @@ def test_explicit_workspace_and_stream(torch):
     assert ei.value.code == -4
 
 
+@pytest.mark.parametrize("win,pw,w", [(4, 20, 24), (7, 22, 30)])
+def test_hip_graph_capture_with_caller_workspace(torch, win, pw, w):
+    """With a caller-owned workspace the launch path allocates nothing and never synchronises, so a call can be captured into
+    a HIP graph and replayed (fold path at 2^20, packed-table tile path at 2^22)."""
+    import blackman_harris_win_amd as bhw
+    p = B.make_params(win, pw, w)
+    n = 1 << pw
+    want = bhw.generate(p, 0, n).clone()                                   # also warms every lazy initialisation
+    ws = torch.empty(B.lib().bhw_workspace_bytes(ctypes.byref(p), 0, n, B.ALGO_AUTO), dtype=torch.uint8, device="cuda")
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        bhw.generate(p, 0, n, out=out, workspace=ws)
+    for _ in range(3):
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert bool((out == want).all())
+
+
 def test_concurrent_streams_use_separate_library_scratch(torch):
     """Two different windows generated concurrently on two streams with library-owned scratch must not share a table."""
     import blackman_harris_win_amd as bhw
