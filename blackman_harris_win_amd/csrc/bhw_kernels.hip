@@ -766,18 +766,33 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
     BHW_TILE_HARMONIC(6)
 #undef BHW_TILE_HARMONIC
 
+    auto final_value = [&](int b, int h, int j) -> int32_t {
+        if constexpr (MODE == 2) return w32_final<BHW_COMBINE_VHDL>(acc[b][h][j], W, win.n_terms);
+        else return (int32_t)((uint32_t)acc[b][h][j] << (32u - W)) >> (32u - W);   // (win_t)(...) wrap to W bits
+    };
+    if (win.apply_x == nullptr) {                                    // wave-uniform
 #pragma unroll
-    for (int b = 0; b < NR; ++b) {
-        const uint32_t r = rr[b];
+        for (int b = 0; b < NR; ++b)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int32_t v;
-                if constexpr (MODE == 2) v = w32_final<BHW_COMBINE_VHDL>(acc[b][h][j], W, win.n_terms);
-                else v = (int32_t)((uint32_t)acc[b][h][j] << (32u - W)) >> (32u - W);   // (win_t)(...) wrap to W bits
-                emit(win, out, r + (uint32_t)h * H + (uint32_t)j * E, v);
-            }
+                for (int j = 0; j < 4; ++j) out[(uint64_t)(rr[b] + (uint32_t)h * H + (uint32_t)j * E)] = final_value(b, h, j);
+    } else {
+        // Fused apply (emit()): one run at a time, its eight x samples fetched together before they are used
+#pragma unroll
+        for (int b = 0; b < NR; ++b) {
+            int32_t xv[2][4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xv[h][j] = win.apply_x[(uint64_t)(rr[b] + (uint32_t)h * H + (uint32_t)j * E)];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    out[(uint64_t)(rr[b] + (uint32_t)h * H + (uint32_t)j * E)] =
+                        (int32_t)(((int64_t)xv[h][j] * (int64_t)final_value(b, h, j)) >> win.apply_shift);
+        }
     }
 }
 

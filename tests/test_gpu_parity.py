@@ -433,6 +433,17 @@ def test_fused_apply_matches_oracle(torch, win, pw, w, model, combine, n0, count
     assert np.array_equal(got, want)
 
 
+def test_fused_apply_full_window_tile_path(torch):
+    """The fused multiplier stage on the tile kernels (2^22, packed table): y = (x * w) >> shift with the exact 64-bit product."""
+    import blackman_harris_win_amd as bhw
+    p = B.make_params(7, 22, 30)
+    n = 1 << 22
+    x = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda")
+    y = bhw.apply(p, x, shift=29)
+    w = bhw.generate(p, 0, n)
+    assert bool((((x.to(torch.int64) * w.to(torch.int64)) >> 29).to(torch.int32) == y).all())
+
+
 def test_fused_apply_rejects_aliasing(torch):
     p = B.make_params(4, 12, 24)
     x = torch.zeros(4096, dtype=torch.int32, device="cuda")
