@@ -786,6 +786,9 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) xv[h][j] = win.apply_x[(uint64_t)(rr[b] + (uint32_t)h * H + (uint32_t)j * E)];
+            // all eight in registers before the first store (otherwise each load is sunk next to its use: load, wait, store, eight times)
+            asm volatile("" : "+v"(xv[0][0]), "+v"(xv[0][1]), "+v"(xv[0][2]), "+v"(xv[0][3]),
+                              "+v"(xv[1][0]), "+v"(xv[1][1]), "+v"(xv[1][2]), "+v"(xv[1][3]));
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
