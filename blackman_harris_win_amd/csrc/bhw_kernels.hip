@@ -430,6 +430,24 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
     }
 }
 
+// Table strategy, pass 1, small tables: one lane per entry, the whole chain unrolled in the mad form, plain natural layout.
+// Below ~2^20 entries the shared-prefix kernel is bound by the latency of its serial prefix phase (8.3 us for 2^18 entries);
+// 64 independent chains per wave finish sooner.
+template <int NITER>
+__global__ __launch_bounds__(kBlock) void k_table_build_plain(BhwCordicCfg cfg, uint32_t entries, int2 *__restrict__ table)
+{
+    __shared__ uint32_t lut_s[32];
+    if (threadIdx.x < 32) lut_s[threadIdx.x] = (uint32_t)cfg.lut[threadIdx.x];
+    __syncthreads();
+    const uint32_t u = blockIdx.x * kBlock + threadIdx.x;
+    if (u >= entries) return;
+    int64_t x = cfg.x0, y = cfg.x0;                                              // rotation 0 always adds (z0 >= 0)
+    int32_t z = (int32_t)((u << cfg.z_shl) - lut_s[0]);
+#pragma unroll
+    for (int r = 1; r < NITER; ++r) rot_step(x, y, z, r, lut_s[r]);
+    table[u] = make_int2((int32_t)(x >> cfg.out_shr), (int32_t)(y >> cfg.out_shr));
+}
+
 // ---------------------------------------------------------------------------------------
 // Direct kernel, fast form: one lane per coefficient, K-1 full CORDIC chains per lane in the same
 // 8-instruction rotation step as the table build (no sharing between lanes), rescaled ROM staged in LDS
@@ -1224,6 +1242,19 @@ int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table
     const uint32_t entries = 1u << (c.phi_width - 2 - c.z_shr);
     // shared-prefix kernel: needs whole 64-leaf groups, |x| < 2^33 and a quarter circle <= 2^32
     const bool fits = (c.dat_width + c.out_shr <= 34);
+    if (fits && c.n_iter >= 7 && entries < (1u << 20) && c.tab_dlog == 0 && !c.tab_split) {
+        const dim3 grid(grid_for(entries)), block(kBlock);
+        switch (c.n_iter) {
+#define BHW_CASE(N) case N: hipLaunchKernelGGL(k_table_build_plain<N>, grid, block, 0, st, c, entries, (int2 *)d_table); break;
+            BHW_CASE(7) BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14)
+            BHW_CASE(15) BHW_CASE(16) BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20) BHW_CASE(21) BHW_CASE(22)
+            BHW_CASE(23) BHW_CASE(24) BHW_CASE(25) BHW_CASE(26) BHW_CASE(27) BHW_CASE(28) BHW_CASE(29) BHW_CASE(30)
+            BHW_CASE(31) BHW_CASE(32)
+#undef BHW_CASE
+        default: return (int)hipErrorInvalidValue;
+        }
+        return finish(hipSuccess);
+    }
     if (entries >= 64 && fits && c.n_iter >= 2) {
         BhwBuildPlan plan;
         for (uint32_t k = 0; k < 32; ++k) plan.lut[k] = (uint32_t)c.lut[k];
