@@ -711,6 +711,46 @@ __device__ __forceinline__ void tile_accumulate(const int32_t (&sv)[4], Sum32 (&
     }
 }
 
+// Quadrant fold for whole periods below the tile threshold, plain natural table: lane r in [0, N/4) owns n = r + j*N/4.  The
+// harmonic loop is unrolled (NTERMS) so the K-1 gathers issue together, and the arithmetic is that of the tile kernel
+// (32-bit forms of both cosine-sum rules).
+template <int NTERMS, int MODE>
+__global__ __launch_bounds__(kBlock) void k_table_combine_fold_t(BhwCordicCfg cfg, BhwWinCfg win, const void *__restrict__ table,
+                                                                  int32_t *__restrict__ out)
+{
+    using acc_t = typename std::conditional<MODE == 2, Sum32, int32_t>::type;
+    const uint32_t lq = cfg.phi_width - 2;
+    const uint32_t E = 1u << lq, emask = E - 1u;
+    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= E) return;
+    const uint32_t W = cfg.dat_width;
+    int2 cs[NTERMS];
+#pragma unroll
+    for (int k = 1; k < NTERMS; ++k)
+        cs[k] = reinterpret_cast<const int2 *>(table)[(((uint32_t)k * r) & emask) >> cfg.z_shr];
+    acc_t acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if constexpr (MODE == 2) acc[j] = Sum32{win.aa[0] >> 2, win.aa[0] & 3};
+        else acc[j] = win.aa[0];
+    }
+    int32_t sv[4];
+#define BHW_FOLD_HARMONIC(K)                                                                       \
+    if constexpr (NTERMS > K) {                                                                    \
+        tile_harmonic<K, MODE>(cfg, win.aa[K], W, cs[K], ((uint32_t)K * r) >> lq, sv);             \
+        tile_accumulate<K, 0>(sv, acc);                                                            \
+    }
+    BHW_FOLD_HARMONIC(1) BHW_FOLD_HARMONIC(2) BHW_FOLD_HARMONIC(3) BHW_FOLD_HARMONIC(4) BHW_FOLD_HARMONIC(5) BHW_FOLD_HARMONIC(6)
+#undef BHW_FOLD_HARMONIC
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int32_t v;
+        if constexpr (MODE == 2) v = w32_final<BHW_COMBINE_VHDL>(acc[j], W, NTERMS);
+        else v = (int32_t)((uint32_t)acc[j] << (32u - W)) >> (32u - W);            // (win_t)(...) wrap to W bits
+        emit(win, out, (uint64_t)r + (uint64_t)j * E, v);
+    }
+}
+
 // Lane r in [0, E/2) owns the eight coefficients n = r + h*E/2 + j*E (h = 0,1; j = 0..3).  For even k the
 // two h-images share one gather (k*E/2 is a whole number of quadrants); for odd k the second image reads
 // entry t + E/2, another dense span of the same tile.
@@ -1312,6 +1352,25 @@ int bhwk_table_combine_fold(const BhwLaunch &l, const BhwCordicCfg &c, const Bhw
     BHW_SET_DEVICE(l);
     hipStream_t st = (hipStream_t)l.stream;
     const uint32_t quarter = 1u << (c.phi_width - 2);
+    if (c.tab_dlog == 0 && !c.tab_split) {                          // the usual case: plain natural table
+        const int mode = (w.combine != BHW_COMBINE_HLS) ? 2 : (c.ones_neg ? 1 : 0);
+        const dim3 grid(grid_for(quarter)), block(kBlock);
+#define BHW_FOLD_NT(NT)                                                                                                   \
+        do {                                                                                                              \
+            if (mode == 0)      hipLaunchKernelGGL((k_table_combine_fold_t<NT, 0>), grid, block, 0, st, c, w, (const void *)d_table, d_out); \
+            else if (mode == 1) hipLaunchKernelGGL((k_table_combine_fold_t<NT, 1>), grid, block, 0, st, c, w, (const void *)d_table, d_out); \
+            else                hipLaunchKernelGGL((k_table_combine_fold_t<NT, 2>), grid, block, 0, st, c, w, (const void *)d_table, d_out); \
+        } while (0)
+        switch (w.n_terms) {
+        case 2: BHW_FOLD_NT(2); return finish(hipSuccess);
+        case 3: BHW_FOLD_NT(3); return finish(hipSuccess);
+        case 4: BHW_FOLD_NT(4); return finish(hipSuccess);
+        case 5: BHW_FOLD_NT(5); return finish(hipSuccess);
+        case 7: BHW_FOLD_NT(7); return finish(hipSuccess);
+        default: break;
+        }
+#undef BHW_FOLD_NT
+    }
     hipLaunchKernelGGL(k_table_combine_fold, dim3(grid_for(quarter)), dim3(kBlock), 0, st, c, w, (const void *)d_table, d_out);
     return finish(hipSuccess);
 }
