@@ -239,7 +239,8 @@ def main():
                      "algorithmic_bytes": BYTES_PER_COEFF * count, "per_kernel": per_kernel,
                      "note": "achieved = 4 B x 2^26 coefficients / device time of one step (both kernels of the step: table build + "
                              "tile combine; HIP events on the launch stream); traffic = HBM bytes per step from PMC (profiles/), "
-                             "above the algorithmic bytes because the strategy round-trips a 128 MiB (c,s) table"},
+                             "above the algorithmic bytes because the strategy round-trips the first-quadrant (c,s) table (32 MiB in the "
+                             "residual format, read ~7x by the six harmonics)"},
         "parity_spot_check": parity,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
