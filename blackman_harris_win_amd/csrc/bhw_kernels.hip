@@ -357,14 +357,16 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
         const uint32_t span = 63u << s;                                          // z_last - z_first
         int k = 1;
         bool live = g < n_groups;
-        const int kmax = n_iter < kPrefixMax ? n_iter : kPrefixMax;
+        // unrolled: immediate shifts and scalar ROM words; this serial chain is the latency every workgroup starts with
+        constexpr int kmax = n_iter < kPrefixMax ? n_iter : kPrefixMax;
+#pragma unroll
         for (int kk = 1; kk < kmax; ++kk) {
             if (live) {
                 const int32_t zl = (int32_t)((uint32_t)zf + span);
                 if ((zf < 0) != (zl < 0)) {
                     live = false;                                                // the group splits at rotation kk
                 } else {
-                    rot_step(x, y, zf, kk, lut_s[kk]);
+                    rot_step(x, y, zf, kk, plan.lut[kk]);
                     k = kk + 1;
                 }
             }
