@@ -21,9 +21,10 @@ struct BhwCordicCfg {
     uint32_t ones_neg;    // 1: quadrant map negates with ~v (CPP); 0: -v
     uint32_t wide;        // 1: state needs more than 32 bits
     uint32_t tab_split;   // table layout: 0 natural index u; 1 split by residue class (u%4==0 | u%4==2 | u odd)
-    uint32_t tab_dlog;    // 0: entries are int2 (c, s); 6: packed -- one dword of two int16 differences to the first entry of the
-                          // 64-entry block, block heads as int2 records at tab_coarse
-                          //    (one exact (c, s, dc, ds) record per 2^d entries + linear prediction), see tab_load()
+    uint32_t tab_dlog;    // table format (tab_load() in bhw_kernels.hip): 0 plain int2 (c, s) entries; 6 "delta16" -- one dword of
+                          // two int16 differences to the first entry of the 64-entry block, block heads as int2 records at
+                          // tab_coarse; 7..9 "residual" -- two bytes per entry against a linear predictor, int4 {c, s, dc, ds}
+                          // records every 2^tab_dlog entries at tab_coarse
     const void *tab_coarse;
 };
 
@@ -76,7 +77,7 @@ int bhwk_replicate(const BhwLaunch &l, const int32_t *d_frame, uint64_t frame_le
 int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table /* (c,s) pairs, 2^(PW-2) */);
 int bhwk_table_combine(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table,
                        uint64_t n0, uint64_t count, int32_t *d_out);
-// coarse records for the residual-compressed table (cfg.tab_dlog > 0): int4 {c, s, dc, ds} per 2^tab_dlog entries
+// which packed table formats a configuration admits (delta16; residual cell size, 0 = not applicable)
 bool bhwk_packed_ok(const BhwCordicCfg &c);
 uint32_t bhwk_resid_dlog(const BhwCordicCfg &c);
 // whole period [0, 2^PW) via the quadrant fold (one lane per four coefficients)
