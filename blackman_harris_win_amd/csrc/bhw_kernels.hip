@@ -414,7 +414,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
         // wave-uniform, so each guard is one scalar compare-and-branch.
 #pragma unroll
         for (int k = 1; k < NITER; ++k) {
-            if (k >= k0) rot_step(x, y, z, k, plan.lut[k]);
+            if (k >= kPrefixMax || k >= k0) rot_step(x, y, z, k, plan.lut[k]);   // k0 <= kPrefixMax: no guard (one basic block) beyond it
         }
         const int32_t c = (int32_t)(x >> plan.out_shr), sn = (int32_t)(y >> plan.out_shr);
         const int2 head = make_int2(__builtin_amdgcn_readfirstlane(c), __builtin_amdgcn_readfirstlane(sn));   // leaf 0 of the group
