@@ -264,7 +264,10 @@ __global__ __launch_bounds__(kBlock) void k_table_build(BhwCordicCfg cfg, uint32
 // Valid when |x|,|y| < 2^33 and the quarter circle <= 2^32 (all models at W <= 32; VHDL: W+P <= 34):
 // rotation 0 always adds (z0 >= 0), giving x1 = y1 = x0 and z1 = z0 - lut[0], which fits int32.
 // ---------------------------------------------------------------------------------------
-constexpr int kPrefixMax = 20;      // deepest rotation a 64-leaf group is followed to in phase 1
+#ifndef BHW_PREFIX_MAX
+#define BHW_PREFIX_MAX 20
+#endif
+constexpr int kPrefixMax = BHW_PREFIX_MAX;   // deepest rotation a 64-leaf group is followed to in phase 1
 constexpr int kGroupsPerWg = 64;    // phase 1: at most one group per lane of the first wave (plan.groups_per_wg <= 64)
 constexpr int kBuildThreads = 256;  // phase 2: four waves, 16 groups each
 constexpr int kHeadsMax = 40;       // residual format: cells of one workgroup (4096 entries >> 7 = 32) + 2
