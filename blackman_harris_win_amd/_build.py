@@ -4,6 +4,7 @@
 hipcc cross-compiles without a GPU; the built .so files stay in-tree (git-ignored) so they
 travel to the GPU box with the snapshot.
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -39,10 +40,34 @@ def _run(cmd, cwd=None):
     return r.stdout
 
 
+def _digest(paths, extra=""):
+    """Content hash of the sources a target is built from: unlike mtimes it survives a copy of the tree (the snapshot
+    that goes to the GPU box), so a prebuilt library is rebuilt exactly when a source changed."""
+    h = hashlib.sha256(extra.encode())
+    for path in paths:
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stamp_ok(target, digest):
+    try:
+        with open(target + ".stamp") as f:
+            return os.path.exists(target) and f.read().strip() == digest
+    except OSError:
+        return False
+
+
+def _write_stamp(target, digest):
+    with open(target + ".stamp", "w") as f:
+        f.write(digest + "\n")
+
+
 def build_library(force=False, verbose=False):
     srcs = [os.path.join(CSRC, f) for f in ("bhw_api.cpp", "bhw_kernels.hip", "bhw_rom.c", "bhw_internal.h", "bhw_tables.inc")]
     srcs.append(os.path.join(ROOT, "include", "bhw.h"))
-    if not force and not _newer(LIB, srcs):
+    digest = _digest(srcs, os.environ.get("BHW_EXTRA_FLAGS", ""))
+    if not force and _stamp_ok(LIB, digest):
         return LIB
     rom_o = os.path.join(CSRC, "bhw_rom.o")
     _run(["gcc", "-O2", "-fPIC", "-c", os.path.join(CSRC, "bhw_rom.c"), "-o", rom_o])
@@ -54,18 +79,31 @@ def build_library(force=False, verbose=False):
            "-x", "none", rom_o, quad, "-Wl,-rpath," + os.path.dirname(os.path.realpath(quad)),
            "-o", LIB]
     out = _run(cmd)
+    _write_stamp(LIB, digest)
     if verbose and out:
         print(out)
     return LIB
+
+
+def oracle_stale():
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("bhw_oracle.c", "bhw_oracle.h", "cpu_baseline.c", "Makefile")]
+    return not _stamp_ok(os.path.join(ORACLE_DIR, "liboracle.so"), _digest(srcs))
 
 
 def build_oracle(force=False):
     """Compile oracle/liboracle.so (test infrastructure) and, when the upstream checkout is present,
     oracle/_ref from the reference's own cordic() source.  Building the checker is not using it."""
     args = ["make", "-C", ORACLE_DIR, "REF=" + REFERENCE]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("bhw_oracle.c", "bhw_oracle.h", "cpu_baseline.c", "Makefile")]
     if force:
         _run(["make", "-C", ORACLE_DIR, "clean"])
-    return _run(args)
+    else:   # make compares mtimes; a changed source with an older timestamp must still rebuild
+        for lib in ("liboracle.so", "libcpubaseline.so"):
+            if oracle_stale() and os.path.exists(os.path.join(ORACLE_DIR, lib)):
+                os.remove(os.path.join(ORACLE_DIR, lib))
+    out = _run(args)
+    _write_stamp(os.path.join(ORACLE_DIR, "liboracle.so"), _digest(srcs))
+    return out
 
 
 if __name__ == "__main__":

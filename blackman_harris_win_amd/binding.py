@@ -9,6 +9,8 @@ COMBINE_HLS, COMBINE_VHDL = 0, 1
 SIN_CORDIC, SIN_TAYLOR, SIN_TAYLOR_ALL = 0, 1, 2
 WIN_HAMMING, WIN_HANN, WIN_BH3, WIN_BH4, WIN_BH5, WIN_BH7 = 1, 2, 3, 4, 5, 7
 ALGO_AUTO, ALGO_DIRECT, ALGO_TABLE = 0, 1, 2
+TABLE_BEST, TABLE_PLAIN, TABLE_DELTA16, TABLE_RESIDUAL = 0, 1, 2, 3
+ABI_VERSION = 2
 
 # every symbol include/bhw.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
@@ -16,6 +18,7 @@ ABI_SYMBOLS = (
     "bhw_coeffs_from_float", "bhw_constant_tables", "bhw_generate_device", "bhw_generate_device_ex",
     "bhw_workspace_bytes", "bhw_generate_batched_device", "bhw_sincos_device", "bhw_generate_to_host",
     "bhw_sincos_to_host", "bhw_release_device", "bhw_apply_device", "bhw_atan2_device", "bhw_atan2_to_host",
+    "bhw_prepare_device",
 )
 
 
@@ -45,7 +48,7 @@ class BhwAtan2Params(ctypes.Structure):
 class BhwExec(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("algo", ctypes.c_uint32),
                 ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_uint64),
-                ("event_after_build", ctypes.c_void_p)]
+                ("event_after_build", ctypes.c_void_p), ("table_format", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
 _lib = None
@@ -92,10 +95,14 @@ def lib():
     L.bhw_generate_to_host.argtypes = [P, ci, u64, u64, i32p]
     L.bhw_sincos_to_host.argtypes = [P, ci, u64, u64, i32p, i32p]
     L.bhw_release_device.argtypes = [ci]
+    L.bhw_prepare_device.argtypes = [P, ci, vp]
     L.bhw_apply_device.argtypes = [P, ci, vp, u64, u64, i32p, i32p, u32]
     PA = ctypes.POINTER(BhwAtan2Params)
     L.bhw_atan2_device.argtypes = [PA, ci, vp, u64, i32p, i32p, i32p]
     L.bhw_atan2_to_host.argtypes = [PA, ci, u64, i32p, i32p, i32p]
+    if L.bhw_abi_version() != ABI_VERSION:
+        raise ImportError(f"{path} has ABI version {L.bhw_abi_version()}, this binding needs {ABI_VERSION}: rebuild it "
+                          "(`python -m blackman_harris_win_amd._build --force`)")
     _lib = L
     return L
 

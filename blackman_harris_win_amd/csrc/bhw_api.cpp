@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -160,37 +161,108 @@ void resolve_window(const bhw_params *p, BhwWinCfg &w)
     w.combine = p->combine;
 }
 
-// ---- library-owned scratch, one buffer per (device, stream) ------------------------------------
-// Calls on different streams may run concurrently, so they must not share a table buffer; calls on one
-// stream are ordered by the stream.  Callers that want no allocation in the launch path (graph capture)
-// pass their own workspace through bhw_exec instead.
-struct DeviceScratch {
-    std::map<void *, std::pair<void *, uint64_t>> bufs;   // stream -> (buffer, bytes)
-    // Taylor ROM cache keyed by (W, L)
-    std::map<std::pair<uint32_t, uint32_t>, int32_t *> roms;
+// The calling thread's current device is switched for the duration of an entry point and put back afterwards.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) {
+            err = hipSetDevice(device);
+            switched = (err == hipSuccess);
+        }
+    }
+    ~DeviceGuard()
+    {
+        if (switched && prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
-std::mutex g_mu;
+
+bool stream_is_capturing(void *stream)
+{
+    if (!stream) return false;                               // the legacy default stream cannot be captured
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &st) != hipSuccess) return false;
+    return st != hipStreamCaptureStatusNone;
+}
+
+// ---- library-owned scratch, one buffer per (device, stream) ------------------------------------
+// The table is rebuilt by every call, so two calls that share a buffer must not interleave their launches
+// (A.build, B.build, A.combine would combine A from B's table).  Calls on different streams get different
+// buffers; calls on one (device, stream) -- from any number of host threads, the *_to_host helpers on the
+// NULL stream included -- hold the slot's mutex from before the build launch until after the last launch,
+// and the stream then orders the kernels.  Growing a buffer happens under the same mutex.
+// Callers that want no allocation in the launch path (graph capture) pass their own workspace through
+// bhw_exec, or call bhw_prepare_device first.
+struct Slot {
+    std::mutex mu;
+    void *buf = nullptr;
+    uint64_t bytes = 0;
+};
+struct DeviceScratch {
+    std::map<void *, std::shared_ptr<Slot>> bufs;            // stream -> slot
+    std::map<std::pair<uint32_t, uint32_t>, int32_t *> roms;  // Taylor ROM cache keyed by (W, L)
+};
+std::mutex g_mu;                                              // guards g_scratch's maps (never held across a launch)
 std::map<int, DeviceScratch> g_scratch;
 
-int ensure_scratch(int device, void *stream, uint64_t bytes, void **out)
+std::shared_ptr<Slot> slot_of(int device, void *stream)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    auto &slot = g_scratch[device].bufs[stream];
-    if (slot.second < bytes) {
-        hipError_t e = hipSetDevice(device);
-        if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
-        if (slot.first) {
-            (void)hipStreamSynchronize((hipStream_t)stream);   // earlier launches on this stream may still read it
-            (void)hipFree(slot.first);
-            slot = {nullptr, 0};
-        }
-        void *b = nullptr;
-        e = hipMalloc(&b, bytes);
-        if (e != hipSuccess) return fail_hip(e, "hipMalloc(scratch)");
-        slot = {b, bytes};
+    auto &sp = g_scratch[device].bufs[stream];
+    if (!sp) sp = std::make_shared<Slot>();
+    return sp;
+}
+
+// slot.mu is held by the caller; the current device is `device`
+int ensure_slot_bytes(Slot &slot, void *stream, uint64_t bytes)
+{
+    if (slot.bytes >= bytes) return BHW_OK;
+    if (stream_is_capturing(stream))
+        return fail(BHW_ERR_HIP, "library scratch of this stream must grow to %llu bytes during stream capture: call "
+                    "bhw_prepare_device first or pass bhw_exec.workspace", (unsigned long long)bytes);
+    if (slot.buf) {
+        (void)hipStreamSynchronize((hipStream_t)stream);      // earlier launches on this stream may still read it
+        (void)hipFree(slot.buf);
+        slot.buf = nullptr;
+        slot.bytes = 0;
     }
-    *out = slot.first;
+    void *b = nullptr;
+    const hipError_t e = hipMalloc(&b, bytes);
+    if (e != hipSuccess) return fail_hip(e, "hipMalloc(scratch)");
+    slot.buf = b;
+    slot.bytes = bytes;
     return BHW_OK;
+}
+
+// ---- packed table formats: verified once per configuration ------------------------------------------
+// Whether every (c, s) difference fits its int8 / int16 field is a property of (model, PW, W, PRECISION, format) alone
+// -- the table does not depend on the weights or on the call's range.  The first table build of a configuration in a
+// packed format runs with the kernels' overflow check on and is read back once; the verdict is cached for the process.
+// A configuration that fails falls back to the next wider format, so an overflow can never reach the coefficients.
+enum { kFmtUnknown = 0, kFmtOk = 1, kFmtBad = 2 };
+std::mutex g_fmt_mu;
+std::map<uint64_t, int> g_fmt_verdict;
+
+uint64_t fmt_key(const bhw_params *p, uint32_t dlog)
+{
+    return ((uint64_t)p->model << 40) | ((uint64_t)p->phi_width << 32) | ((uint64_t)p->dat_width << 24) |
+           ((uint64_t)(p->model == BHW_MODEL_VHDL ? p->precision : 0u) << 16) | dlog;
+}
+int fmt_verdict(const bhw_params *p, uint32_t dlog)
+{
+    std::lock_guard<std::mutex> lk(g_fmt_mu);
+    auto it = g_fmt_verdict.find(fmt_key(p, dlog));
+    return it == g_fmt_verdict.end() ? kFmtUnknown : it->second;
+}
+void fmt_set_verdict(const bhw_params *p, uint32_t dlog, int v)
+{
+    std::lock_guard<std::mutex> lk(g_fmt_mu);
+    g_fmt_verdict[fmt_key(p, dlog)] = v;
 }
 
 int get_taylor_rom(int device, void *stream, uint32_t W, uint32_t L, const int32_t **rom)
@@ -200,16 +272,16 @@ int get_taylor_rom(int device, void *stream, uint32_t W, uint32_t L, const int32
     auto key = std::make_pair(W, L);
     auto it = s.roms.find(key);
     if (it != s.roms.end()) { *rom = it->second; return BHW_OK; }
-    hipError_t e = hipSetDevice(device);
-    if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+    if (stream_is_capturing(stream))
+        return fail(BHW_ERR_HIP, "the Taylor ROM for dat_width %u / lut_size %u is not on the device yet and the stream is "
+                    "capturing: call bhw_prepare_device first", W, L);
     std::vector<int32_t> host(2u << L);
     bhw_taylor_rom(W, L, host.data());
     int32_t *d = nullptr;
-    e = hipMalloc((void **)&d, host.size() * sizeof(int32_t));
+    hipError_t e = hipMalloc((void **)&d, host.size() * sizeof(int32_t));
     if (e != hipSuccess) return fail_hip(e, "hipMalloc(rom)");
-    e = hipMemcpy(d, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    e = hipMemcpy(d, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice);   // synchronous: once per (device, W, L)
     if (e != hipSuccess) { (void)hipFree(d); return fail_hip(e, "hipMemcpy(rom)"); }
-    (void)stream;
     s.roms[key] = d;
     *rom = d;
     return BHW_OK;
@@ -277,16 +349,84 @@ int run_split(const BhwLaunch &l, uint64_t n0, uint64_t count, uint64_t N, bool 
     return e ? fail_hip(e, "tail launch") : BHW_OK;
 }
 
+uint32_t exec_table_format(const bhw_exec *ex)
+{
+    return (ex && ex->struct_size >= sizeof(bhw_exec)) ? ex->table_format : (uint32_t)BHW_TABLE_BEST;
+}
+
+int check_exec(const bhw_exec *ex)
+{
+    if (!ex) return BHW_OK;
+    if (ex->struct_size != sizeof(bhw_exec) && ex->struct_size != 32u)       // 32 = the ABI-1 layout (no table_format)
+        return fail(BHW_ERR_BADARG, "bhw_exec.struct_size %u", ex->struct_size);
+    if (ex->struct_size >= sizeof(bhw_exec) && (ex->table_format > BHW_TABLE_RESIDUAL || ex->reserved != 0))
+        return fail(BHW_ERR_BADARG, "bhw_exec.table_format %u / reserved %u", ex->table_format, ex->reserved);
+    return BHW_OK;
+}
+
+// Table formats a tiled whole-period call may use, narrowest first (tab_dlog values: 7..9 residual, 6 delta16, 0 plain).
+// The packed build variants exist from 21 rotations on (always true at PW >= 22).
+int table_format_candidates(const BhwCordicCfg &c, bool tiled, uint32_t limit, uint32_t out[3])
+{
+    int n = 0;
+    if (tiled && c.n_iter >= 21) {
+        const uint32_t d = bhwk_resid_dlog(c);
+        if (d && (limit == BHW_TABLE_BEST || limit == BHW_TABLE_RESIDUAL)) out[n++] = d;
+        if (bhwk_packed_ok(c) && limit != BHW_TABLE_PLAIN) out[n++] = 6u;
+    }
+    out[n++] = 0u;
+    return n;
+}
+
+// Build the table in the narrowest format that is exact for this configuration.  A packed format whose exactness has not
+// been established yet for the configuration is built with the kernels' overflow check on and read back here (once per
+// process and configuration; during stream capture the plain format is used instead).  `ws` holds E*8 bytes:
+// [ entries | ... | records / block heads at byte offset E*4 | ... | check word in the last 8 bytes ].
+int build_table(const bhw_params *p, const BhwLaunch &l, BhwCordicCfg &c, bool tiled, uint32_t limit, void *ws)
+{
+    uint32_t cand[3];
+    const int n_cand = table_format_candidates(c, tiled, limit, cand);
+    const uint64_t E = table_entries(c);
+    for (int i = 0; i < n_cand; ++i) {
+        const uint32_t dlog = cand[i];
+        int verdict = dlog ? fmt_verdict(p, dlog) : (int)kFmtOk;
+        if (verdict == kFmtBad) continue;
+        if (verdict == kFmtUnknown && stream_is_capturing(l.stream)) continue;   // no read-back inside a capture
+        c.tab_dlog = dlog;
+        c.tab_coarse = dlog ? (const void *)((const char *)ws + E * 4ull) : nullptr;
+        c.tab_check = nullptr;
+        if (verdict == kFmtUnknown) {
+            c.tab_check = (uint32_t *)((char *)ws + E * 8ull - 8ull);
+            const hipError_t he = hipMemsetAsync(c.tab_check, 0, 8, (hipStream_t)l.stream);
+            if (he != hipSuccess) return fail_hip(he, "hipMemsetAsync(check word)");
+        }
+        const int e = bhwk_table_build(l, c, (int32_t *)ws);
+        if (e) return fail_hip(e, "table build launch");
+        if (verdict == kFmtOk) return BHW_OK;
+        uint32_t flag = 1;
+        hipError_t he = hipMemcpyAsync(&flag, c.tab_check, sizeof flag, hipMemcpyDeviceToHost, (hipStream_t)l.stream);
+        if (he == hipSuccess) he = hipStreamSynchronize((hipStream_t)l.stream);
+        if (he != hipSuccess) return fail_hip(he, "read-back of the table format check");
+        c.tab_check = nullptr;
+        fmt_set_verdict(p, dlog, flag ? kFmtBad : kFmtOk);
+        if (!flag) return BHW_OK;                                                // exact: keep the table just built
+    }
+    return fail(BHW_ERR_HIP, "no table format applies");                         // unreachable: plain is always a candidate
+}
+
 int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, uint64_t count, int32_t *d_out,
                   const bhw_exec *ex, const int32_t *apply_x = nullptr, uint32_t apply_shift = 0)
 {
     int rc = validate(p);
     if (rc) return rc;
     if (count && !d_out) return fail(BHW_ERR_BADARG, "d_out is NULL");
-    if (ex && ex->struct_size != sizeof(bhw_exec)) return fail(BHW_ERR_BADARG, "bhw_exec.struct_size");
+    rc = check_exec(ex);
+    if (rc) return rc;
     if (!count) return BHW_OK;
     if (count > (1ull << 34)) return fail(BHW_ERR_BADARG, "count %llu > 2^34 per call", (unsigned long long)count);
     if (!device_ok(device)) return fail(BHW_ERR_HIP, "no usable HIP device %d (this library has no CPU path)", device);
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
     BhwLaunch l{device, stream};
     BhwWinCfg w;
     resolve_window(p, w);
@@ -320,14 +460,19 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
     }
     const uint64_t need = table_entries(c) * 8ull;
     void *ws = nullptr;
+    std::shared_ptr<Slot> slot;
+    std::unique_lock<std::mutex> slot_lock;                  // held until every launch of this call is enqueued
     if (ex && ex->workspace) {
         if (ex->workspace_bytes < need)
             return fail(BHW_ERR_WORKSPACE, "workspace %llu < %llu bytes", (unsigned long long)ex->workspace_bytes,
                         (unsigned long long)need);
         ws = ex->workspace;
     } else {
-        rc = ensure_scratch(device, stream, need, &ws);
+        slot = slot_of(device, stream);
+        slot_lock = std::unique_lock<std::mutex>(slot->mu);
+        rc = ensure_slot_bytes(*slot, stream, need);
         if (rc) return rc;
+        ws = slot->buf;
     }
     // head | whole periods | tail over the one table built here: the whole periods take the fold / tile kernels, the
     // ragged ends the general gather kernel
@@ -337,17 +482,9 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
     c.tab_split = (tiled && c.z_shr == 0) ? 1u : 0u;
     // whole-period tile tables are stored packed when the widths allow it (formats in bhw_kernels.hip): "residual" = 2 bytes per
     // entry + one int4 record per 2^d entries, else "delta16" = 4 bytes per entry + one int2 head per 64 entries, else the plain
-    // 8 bytes per entry.  The combine pass is bound by table + output traffic as much as by arithmetic.  Entries and records live
-    // in the same scratch: [ entries | ... | records at byte offset E * 4 ].
-    // BHW_TABLE_PACK in the environment: 0 = plain, 1 = at most delta16, unset / 2 = best (A/B and equivalence tests).
-    static const int pack = [] { const char *e = getenv("BHW_TABLE_PACK"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }();
-    c.tab_dlog = 0u;
-    if (tiled && pack >= 2) c.tab_dlog = bhwk_resid_dlog(c);
-    if (tiled && pack >= 1 && c.tab_dlog == 0u && bhwk_packed_ok(c)) c.tab_dlog = 6u;
-    if (c.n_iter < 21) c.tab_dlog = 0u;                     // the packed build variants exist from 21 rotations on (always true at PW >= 22)
-    c.tab_coarse = c.tab_dlog ? (const void *)((const char *)ws + table_entries(c) * 4ull) : nullptr;
-    int e = bhwk_table_build(l, c, (int32_t *)ws);
-    if (e) return fail_hip(e, "table build launch");
+    // 8 bytes per entry.  The combine pass is bound by table + output traffic as much as by arithmetic.
+    rc = build_table(p, l, c, tiled, exec_table_format(ex), ws);
+    if (rc) return rc;
     if (ex && ex->event_after_build) {
         hipError_t he = hipEventRecord((hipEvent_t)ex->event_after_build, (hipStream_t)stream);
         if (he != hipSuccess) return fail_hip(he, "hipEventRecord(event_after_build)");
@@ -480,6 +617,8 @@ int bhw_generate_batched_device(const bhw_params *p, int device, void *hip_strea
     // frame 0 is generated in place, then replicated into frames 1..frames-1
     rc = generate_impl(p, device, hip_stream, 0, N, d_out, nullptr);
     if (rc || frames == 1) return rc;
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
     BhwLaunch l{device, hip_stream};
     int e = bhwk_replicate(l, d_out, N, frames - 1, d_out + N);
     return e ? fail_hip(e, "replicate launch") : BHW_OK;
@@ -493,6 +632,8 @@ int bhw_sincos_device(const bhw_params *p, int device, void *hip_stream, uint64_
     if (!count) return BHW_OK;
     if (!d_sin && !d_cos) return fail(BHW_ERR_BADARG, "both outputs NULL");
     if (!device_ok(device)) return fail(BHW_ERR_HIP, "no usable HIP device %d (this library has no CPU path)", device);
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
     BhwLaunch l{device, hip_stream};
     if (p->sin_type != BHW_SIN_CORDIC) {
         BhwTaylorCfg t;
@@ -528,10 +669,10 @@ int bhw_generate_to_host(const bhw_params *p, int device, uint64_t n0, uint64_t 
     if (!count) return BHW_OK;
     if (!h_out) return fail(BHW_ERR_BADARG, "h_out is NULL");
     if (!device_ok(device)) return fail(BHW_ERR_HIP, "no usable HIP device %d (this library has no CPU path)", device);
-    hipError_t e = hipSetDevice(device);
-    if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
     int32_t *d = nullptr;
-    e = hipMalloc((void **)&d, count * sizeof(int32_t));
+    hipError_t e = hipMalloc((void **)&d, count * sizeof(int32_t));
     if (e != hipSuccess) return fail_hip(e, "hipMalloc(out)");
     rc = generate_impl(p, device, nullptr, n0, count, d, nullptr);
     if (!rc) {
@@ -549,10 +690,10 @@ int bhw_sincos_to_host(const bhw_params *p, int device, uint64_t theta0, uint64_
     if (!count) return BHW_OK;
     if (!h_sin && !h_cos) return fail(BHW_ERR_BADARG, "both outputs NULL");
     if (!device_ok(device)) return fail(BHW_ERR_HIP, "no usable HIP device %d (this library has no CPU path)", device);
-    hipError_t e = hipSetDevice(device);
-    if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
     int32_t *d = nullptr;
-    e = hipMalloc((void **)&d, 2 * count * sizeof(int32_t));
+    hipError_t e = hipMalloc((void **)&d, 2 * count * sizeof(int32_t));
     if (e != hipSuccess) return fail_hip(e, "hipMalloc(out)");
     rc = bhw_sincos_device(p, device, nullptr, theta0, count, d, d + count);
     if (!rc && h_sin) {
@@ -577,6 +718,7 @@ int bhw_dbg_table_build(const bhw_params *p, int device, void *stream, void *ws)
     BhwWinCfg w;
     resolve_window(p, w);
     c.tab_split = (bhwk_tile_applicable(c, w) && c.z_shr == 0) ? 1u : 0u;
+    DeviceGuard guard(device);
     BhwLaunch l{device, stream};
     return bhwk_table_build(l, c, (int32_t *)ws);
 }
@@ -588,12 +730,55 @@ int bhw_dbg_table_combine(const bhw_params *p, int device, void *stream, const v
     resolve_cordic(p, c);
     BhwWinCfg w;
     resolve_window(p, w);
+    DeviceGuard guard(device);
     BhwLaunch l{device, stream};
     if (bhwk_tile_applicable(c, w)) {
         c.tab_split = c.z_shr == 0 ? 1u : 0u;
         return bhwk_table_combine_tile(l, c, w, (const int32_t *)ws, d_out);
     }
     return bhwk_table_combine_fold(l, c, w, (const int32_t *)ws, d_out);
+}
+
+// Builds the table of `p` in the packed format `dlog` (6 delta16, 7..9 residual) with the overflow check on, whether or not
+// the format would be chosen for this configuration, and returns the check word.  `ws`: bhw_workspace_bytes(TABLE) bytes.
+int bhw_dbg_check_table_format(const bhw_params *p, int device, void *stream, uint32_t dlog, void *ws, uint32_t *flag_out)
+{
+    if (validate(p) || !ws || !flag_out || dlog < 6 || dlog > 9) return BHW_ERR_BADARG;
+    BhwCordicCfg c;
+    resolve_cordic(p, c);
+    if (c.z_shr != 0 || c.n_iter < 21 || c.dat_width + c.out_shr > 34 || table_entries(c) < (1ull << 12)) return BHW_ERR_UNSUPPORTED;
+    DeviceGuard guard(device);
+    const uint64_t E = table_entries(c);
+    c.tab_split = 1u;
+    c.tab_dlog = dlog;
+    c.tab_coarse = (const char *)ws + E * 4ull;
+    c.tab_check = (uint32_t *)((char *)ws + E * 8ull - 8ull);
+    hipError_t he = hipMemsetAsync(c.tab_check, 0, 8, (hipStream_t)stream);
+    if (he != hipSuccess) return BHW_ERR_HIP;
+    BhwLaunch l{device, stream};
+    if (bhwk_table_build(l, c, (int32_t *)ws)) return BHW_ERR_HIP;
+    he = hipMemcpyAsync(flag_out, c.tab_check, 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (he == hipSuccess) he = hipStreamSynchronize((hipStream_t)stream);
+    return he == hipSuccess ? BHW_OK : BHW_ERR_HIP;
+}
+
+// Verdict cache of the packed formats (0 unknown, 1 exact, 2 overflows); set != 0 overrides it (tests of the fallback).
+int bhw_dbg_table_format_verdict(const bhw_params *p, uint32_t dlog, int set)
+{
+    if (validate(p)) return BHW_ERR_BADARG;
+    if (set) fmt_set_verdict(p, dlog, set);
+    return fmt_verdict(p, dlog);
+}
+
+// tab_dlog the residual format would use for `p` (0: not applicable) and whether delta16 applies
+int bhw_dbg_table_format_info(const bhw_params *p, uint32_t *resid_dlog, uint32_t *delta16_ok)
+{
+    if (validate(p)) return BHW_ERR_BADARG;
+    BhwCordicCfg c;
+    resolve_cordic(p, c);
+    if (resid_dlog) *resid_dlog = c.n_iter >= 21 ? bhwk_resid_dlog(c) : 0u;
+    if (delta16_ok) *delta16_ok = (c.n_iter >= 21 && bhwk_packed_ok(c)) ? 1u : 0u;
+    return BHW_OK;
 }
 
 static int validate_atan2(const bhw_atan2_params *p)
@@ -617,6 +802,8 @@ int bhw_atan2_device(const bhw_atan2_params *p, int device, void *hip_stream, ui
     if (!count) return BHW_OK;
     if (!d_x || !d_y || !d_phi) return fail(BHW_ERR_BADARG, "d_x / d_y / d_phi is NULL");
     if (!device_ok(device)) return fail(BHW_ERR_HIP, "no usable HIP device %d (this library has no CPU path)", device);
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
     BhwAtan2Cfg c;
     memset(&c, 0, sizeof c);
     c.precision = p->precision;
@@ -636,10 +823,10 @@ int bhw_atan2_to_host(const bhw_atan2_params *p, int device, uint64_t count, con
     if (!count) return BHW_OK;
     if (!h_x || !h_y || !h_phi) return fail(BHW_ERR_BADARG, "h_x / h_y / h_phi is NULL");
     if (!device_ok(device)) return fail(BHW_ERR_HIP, "no usable HIP device %d (this library has no CPU path)", device);
-    hipError_t e = hipSetDevice(device);
-    if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
     int32_t *d = nullptr;
-    e = hipMalloc((void **)&d, 3 * count * sizeof(int32_t));
+    hipError_t e = hipMalloc((void **)&d, 3 * count * sizeof(int32_t));
     if (e != hipSuccess) return fail_hip(e, "hipMalloc(atan2)");
     e = hipMemcpy(d, h_x, count * sizeof(int32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d + count, h_y, count * sizeof(int32_t), hipMemcpyHostToDevice);
@@ -655,17 +842,58 @@ int bhw_atan2_to_host(const bhw_atan2_params *p, int device, uint64_t count, con
 
 int bhw_release_device(int device)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    auto it = g_scratch.find(device);
-    if (it == g_scratch.end()) return BHW_OK;
-    if (hipSetDevice(device) == hipSuccess) {
-        (void)hipDeviceSynchronize();
-        for (auto &kv : it->second.bufs)
-            if (kv.second.first) (void)hipFree(kv.second.first);
-        for (auto &kv : it->second.roms) (void)hipFree(kv.second);
+    DeviceScratch taken;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_scratch.find(device);
+        if (it == g_scratch.end()) return BHW_OK;
+        taken = std::move(it->second);
+        g_scratch.erase(it);
     }
-    g_scratch.erase(it);
+    DeviceGuard guard(device);
+    if (guard.err == hipSuccess) {
+        (void)hipDeviceSynchronize();
+        for (auto &kv : taken.bufs) {
+            std::lock_guard<std::mutex> lk(kv.second->mu);   // a call still enqueueing on this slot finishes first
+            if (kv.second->buf) (void)hipFree(kv.second->buf);
+            kv.second->buf = nullptr;
+            kv.second->bytes = 0;
+        }
+        for (auto &kv : taken.roms) (void)hipFree(kv.second);
+    }
     return BHW_OK;
+}
+
+int bhw_prepare_device(const bhw_params *p, int device, void *hip_stream)
+{
+    int rc = validate(p, true);
+    if (rc) return rc;
+    if (!device_ok(device)) return fail(BHW_ERR_HIP, "no usable HIP device %d (this library has no CPU path)", device);
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
+    if (p->sin_type != BHW_SIN_CORDIC) {
+        BhwTaylorCfg t;
+        return resolve_taylor(p, device, hip_stream, t);        // uploads the ROM on first use
+    }
+    if (p->model > BHW_MODEL_VHDL) return BHW_OK;               // variant generators: nothing lazy
+    BhwCordicCfg c;
+    resolve_cordic(p, c);
+    BhwWinCfg w;
+    resolve_window(p, w);
+    const uint64_t need = table_entries(c) * 8ull;
+    auto slot = slot_of(device, hip_stream);
+    std::unique_lock<std::mutex> lk(slot->mu);
+    rc = ensure_slot_bytes(*slot, hip_stream, need);
+    if (rc) return rc;
+    // settle the packed-format verdicts of this configuration (build_table reads the check word back when one is open)
+    if (bhwk_tile_applicable(c, w)) {
+        BhwLaunch l{device, hip_stream};
+        c.tab_split = c.z_shr == 0 ? 1u : 0u;
+        rc = build_table(p, l, c, true, BHW_TABLE_BEST, slot->buf);
+        if (rc) return rc;
+    }
+    const hipError_t he = hipStreamSynchronize((hipStream_t)hip_stream);
+    return he == hipSuccess ? BHW_OK : fail_hip(he, "hipStreamSynchronize");
 }
 
 } // extern "C"

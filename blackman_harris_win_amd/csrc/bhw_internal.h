@@ -26,6 +26,7 @@ struct BhwCordicCfg {
                           // tab_coarse; 7..9 "residual" -- two bytes per entry against a linear predictor, int4 {c, s, dc, ds}
                           // records every 2^tab_dlog entries at tab_coarse
     const void *tab_coarse;
+    uint32_t *tab_check;  // build pass, packed formats: device word set to 1 when an entry does not fit its field (NULL: no check)
 };
 
 // Cosine-sum stage.

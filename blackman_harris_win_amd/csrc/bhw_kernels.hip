@@ -108,6 +108,12 @@ __device__ __forceinline__ int2 tab_predict(const int4 rec, uint32_t f, uint32_t
     return make_int2(rec.x + (__mul24(rec.z, (int32_t)f) >> d), rec.y + (__mul24(rec.w, (int32_t)f) >> d));   // |dc|, |ds| < 2^17, f < 2^9
 }
 
+// v representable as a two's-complement field of `bits` bits
+__device__ __forceinline__ bool fits_bits(int32_t v, uint32_t bits)
+{
+    return (uint32_t)(v + (1 << (bits - 1))) < (1u << bits);
+}
+
 // FMT: -1 format read from cfg.tab_dlog at run time, 0 plain int2 entries, 1 delta16, 2 residual.
 template <int KCLASS = 0, int FMT = -1, int SPLIT = -1>
 __device__ __forceinline__ int2 tab_load(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t log2_entries)
@@ -129,17 +135,21 @@ __device__ __forceinline__ int2 tab_load(const BhwCordicCfg &cfg, const void *__
 // `rec` = the residual format's record of u's cell (wave-uniform: a 64-entry block lies inside one cell).
 template <int FMT = -1>
 __device__ __forceinline__ void tab_store(void *__restrict__ table, uint32_t u, uint32_t log2_entries, uint32_t split, uint32_t dlog,
-                                          void *coarse, int32_t c, int32_t s, int2 head, int4 rec)
+                                          void *coarse, int32_t c, int32_t s, int2 head, int4 rec, uint32_t *check_flag)
 {
     const uint32_t idx = tab_index(u, log2_entries, split);
     if (FMT == 0 || (FMT < 0 && dlog == 0)) {
         reinterpret_cast<int2 *>(table)[idx] = make_int2(c, s);
     } else if (FMT == 1 || (FMT < 0 && dlog == kPackLog)) {
-        reinterpret_cast<uint32_t *>(table)[idx] = ((uint32_t)(c - head.x) & 0xFFFFu) | ((uint32_t)(s - head.y) << 16);
+        const int32_t dc = c - head.x, ds = s - head.y;
+        if (check_flag && !(fits_bits(dc, 16) && fits_bits(ds, 16))) atomicOr(check_flag, 1u);
+        reinterpret_cast<uint32_t *>(table)[idx] = ((uint32_t)dc & 0xFFFFu) | ((uint32_t)ds << 16);
         if ((u & ((1u << kPackLog) - 1u)) == 0u) reinterpret_cast<int2 *>(coarse)[u >> kPackLog] = make_int2(c, s);
     } else {
         const int2 p = tab_predict(rec, u & ((1u << dlog) - 1u), dlog);
-        reinterpret_cast<uint16_t *>(table)[idx] = (uint16_t)(((uint32_t)(c - p.x) & 0xFFu) | (((uint32_t)(s - p.y) & 0xFFu) << 8));
+        const int32_t dc = c - p.x, ds = s - p.y;
+        if (check_flag && !(fits_bits(dc, 8) && fits_bits(ds, 8))) atomicOr(check_flag, 1u);
+        reinterpret_cast<uint16_t *>(table)[idx] = (uint16_t)(((uint32_t)dc & 0xFFu) | (((uint32_t)ds & 0xFFu) << 8));
     }
 }
 
@@ -245,7 +255,8 @@ __global__ __launch_bounds__(kBlock) void k_table_build(BhwCordicCfg cfg, uint32
     // a wave holds one aligned 64-entry block (the packed format needs entries >= 64, see bhwk_packed_ok)
     const int2 head = make_int2(__builtin_amdgcn_readfirstlane(c), __builtin_amdgcn_readfirstlane(sn));
     const int4 rec = cfg.tab_dlog > kPackLog ? reinterpret_cast<const int4 *>(cfg.tab_coarse)[u >> cfg.tab_dlog] : make_int4(0, 0, 0, 0);
-    tab_store(table, u, cfg.phi_width - 2 - cfg.z_shr, cfg.tab_split, cfg.tab_dlog, const_cast<void *>(cfg.tab_coarse), c, sn, head, rec);
+    tab_store(table, u, cfg.phi_width - 2 - cfg.z_shr, cfg.tab_split, cfg.tab_dlog, const_cast<void *>(cfg.tab_coarse), c, sn, head, rec,
+              cfg.tab_check);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -286,6 +297,7 @@ struct BhwBuildPlan {
     uint32_t groups_per_wg;   // 4, 16 or 64: small tables use small workgroups so the grid still fills the chip
     uint32_t pad;
     int64_t  x0;
+    uint32_t *check_flag;     // packed formats: set to 1 when a difference does not fit its field (NULL: configuration already verified)
 };
 
 // lut[k] < 2^23 for every k >= 9 whenever the fast path is legal (lut[k] <= atan(2^-k) 2^33 / pi), so the
@@ -425,12 +437,16 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
         if constexpr (FMT == 0) {
             reinterpret_cast<int2 *>(table)[idx] = make_int2(c, sn);
         } else if constexpr (FMT == 1) {
-            reinterpret_cast<uint32_t *>(table)[idx] = ((uint32_t)(c - head.x) & 0xFFFFu) | ((uint32_t)(sn - head.y) << 16);
+            const int32_t dc = c - head.x, ds = sn - head.y;
+            if (plan.check_flag && !(fits_bits(dc, 16) && fits_bits(ds, 16))) atomicOr(plan.check_flag, 1u);   // scalar guard: verified configurations skip it
+            reinterpret_cast<uint32_t *>(table)[idx] = ((uint32_t)dc & 0xFFFFu) | ((uint32_t)ds << 16);
             if (lane == 0u) reinterpret_cast<int2 *>(const_cast<void *>(plan.tab_coarse))[g] = head;   // block = group
         } else {
             const int4 rec = record((g << 6) >> d);                                                     // wave-uniform
             const int2 p = tab_predict(rec, ((g << 6) & ((1u << d) - 1u)) + lane, d);
-            reinterpret_cast<uint16_t *>(table)[idx] = (uint16_t)(((uint32_t)(c - p.x) & 0xFFu) | (((uint32_t)(sn - p.y) & 0xFFu) << 8));
+            const int32_t dc = c - p.x, ds = sn - p.y;
+            if (plan.check_flag && !(fits_bits(dc, 8) && fits_bits(ds, 8))) atomicOr(plan.check_flag, 1u);
+            reinterpret_cast<uint16_t *>(table)[idx] = (uint16_t)(((uint32_t)dc & 0xFFu) | (((uint32_t)ds & 0xFFu) << 8));
         }
     }
 }
@@ -1176,19 +1192,32 @@ __global__ __launch_bounds__(kBlock) void k_taylor_sincos(BhwTaylorCfg t, uint64
 
 inline unsigned grid_for(uint64_t count) { return (unsigned)((count + kBlock - 1) / kBlock); }
 
+// Launches go through hipLaunchKernel, which returns the launch status itself: the thread's hipGetLastError() state is
+// neither read nor cleared here, so an error left behind by another library is not swallowed and not blamed on this call.
+// The API layer (bhw_api.cpp) has already made l.device the current device.
+thread_local hipError_t t_launch_err = hipSuccess;
+
+template <typename T> struct same_type { using type = T; };
+
+template <typename... KArgs>
+inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, hipStream_t st, typename same_type<KArgs>::type... args)
+{
+    void *ptrs[] = {(void *)&args...};
+    const hipError_t e = hipLaunchKernel(reinterpret_cast<const void *>(kernel), grid, block, ptrs, 0, st);
+    if (e != hipSuccess && t_launch_err == hipSuccess) t_launch_err = e;
+}
+#define BHW_LAUNCH(kernel, grid, block, shmem, st, ...) launch(kernel, grid, block, st, __VA_ARGS__)
+
 inline int finish(hipError_t e)
 {
-    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = t_launch_err;
+    t_launch_err = hipSuccess;
     return (int)e;
 }
 
 } // namespace
 
-#define BHW_SET_DEVICE(l)                                   \
-    do {                                                    \
-        hipError_t e__ = hipSetDevice((l).device);          \
-        if (e__ != hipSuccess) return (int)e__;             \
-    } while (0)
+#define BHW_SET_DEVICE(l) ((void)(l))
 
 int bhwk_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, uint64_t n0, uint64_t count, int32_t *d_out)
 {
@@ -1198,7 +1227,7 @@ int bhwk_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, u
     if (c.dat_width + c.out_shr <= 34 && c.n_iter >= 7) {   // |x| < 2^33, quarter circle <= 2^32: the mad-form rotation applies
         const dim3 grid(grid_for(count)), block(kBlock);
         switch (c.n_iter) {
-#define BHW_CASE(N) case N: hipLaunchKernelGGL(k_direct_fast<N>, grid, block, 0, st, c, w, n0, count, d_out); break;
+#define BHW_CASE(N) case N: BHW_LAUNCH(k_direct_fast<N>, grid, block, 0, st, c, w, n0, count, d_out); break;
             BHW_CASE(7) BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14)
             BHW_CASE(15) BHW_CASE(16) BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20) BHW_CASE(21) BHW_CASE(22)
             BHW_CASE(23) BHW_CASE(24) BHW_CASE(25) BHW_CASE(26) BHW_CASE(27) BHW_CASE(28) BHW_CASE(29) BHW_CASE(30)
@@ -1208,8 +1237,8 @@ int bhwk_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, u
         }
         return finish(hipSuccess);
     }
-    if (c.wide) hipLaunchKernelGGL(k_direct<int64_t>, dim3(grid_for(count)), dim3(kBlock), 0, st, c, w, n0, count, d_out);
-    else        hipLaunchKernelGGL(k_direct<int32_t>, dim3(grid_for(count)), dim3(kBlock), 0, st, c, w, n0, count, d_out);
+    if (c.wide) BHW_LAUNCH(k_direct<int64_t>, dim3(grid_for(count)), dim3(kBlock), 0, st, c, w, n0, count, d_out);
+    else        BHW_LAUNCH(k_direct<int32_t>, dim3(grid_for(count)), dim3(kBlock), 0, st, c, w, n0, count, d_out);
     return finish(hipSuccess);
 }
 
@@ -1221,7 +1250,7 @@ int bhwk_sincos(const BhwLaunch &l, const BhwCordicCfg &c, uint64_t theta0, uint
     if (c.dat_width + c.out_shr <= 34 && c.n_iter >= 7) {
         const dim3 grid(grid_for(count)), block(kBlock);
         switch (c.n_iter) {
-#define BHW_CASE(N) case N: hipLaunchKernelGGL(k_sincos_fast<N>, grid, block, 0, st, c, theta0, count, d_sin, d_cos); break;
+#define BHW_CASE(N) case N: BHW_LAUNCH(k_sincos_fast<N>, grid, block, 0, st, c, theta0, count, d_sin, d_cos); break;
             BHW_CASE(7) BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14)
             BHW_CASE(15) BHW_CASE(16) BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20) BHW_CASE(21) BHW_CASE(22)
             BHW_CASE(23) BHW_CASE(24) BHW_CASE(25) BHW_CASE(26) BHW_CASE(27) BHW_CASE(28) BHW_CASE(29) BHW_CASE(30)
@@ -1231,8 +1260,8 @@ int bhwk_sincos(const BhwLaunch &l, const BhwCordicCfg &c, uint64_t theta0, uint
         }
         return finish(hipSuccess);
     }
-    if (c.wide) hipLaunchKernelGGL(k_sincos<int64_t>, dim3(grid_for(count)), dim3(kBlock), 0, st, c, theta0, count, d_sin, d_cos);
-    else        hipLaunchKernelGGL(k_sincos<int32_t>, dim3(grid_for(count)), dim3(kBlock), 0, st, c, theta0, count, d_sin, d_cos);
+    if (c.wide) BHW_LAUNCH(k_sincos<int64_t>, dim3(grid_for(count)), dim3(kBlock), 0, st, c, theta0, count, d_sin, d_cos);
+    else        BHW_LAUNCH(k_sincos<int32_t>, dim3(grid_for(count)), dim3(kBlock), 0, st, c, theta0, count, d_sin, d_cos);
     return finish(hipSuccess);
 }
 
@@ -1253,8 +1282,8 @@ int bhwk_replicate(const BhwLaunch &l, const int32_t *d_frame, uint64_t frame_le
     if (gy > frames) gy = frames;
     if (gy < 1) gy = 1;
     if (gy > 65535) gy = 65535;
-    if (vec) hipLaunchKernelGGL(k_replicate16, dim3(gx, gy), dim3(kBlock), 0, st, (const int4 *)d_frame, items, frames, (int4 *)d_out);
-    else     hipLaunchKernelGGL(k_replicate4, dim3(gx, gy), dim3(kBlock), 0, st, d_frame, items, frames, d_out);
+    if (vec) BHW_LAUNCH(k_replicate16, dim3(gx, gy), dim3(kBlock), 0, st, (const int4 *)d_frame, items, frames, (int4 *)d_out);
+    else     BHW_LAUNCH(k_replicate4, dim3(gx, gy), dim3(kBlock), 0, st, d_frame, items, frames, d_out);
     return finish(hipSuccess);
 }
 
@@ -1290,7 +1319,7 @@ int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table
     if (fits && c.n_iter >= 7 && entries < (1u << 20) && c.tab_dlog == 0 && !c.tab_split) {
         const dim3 grid(grid_for(entries)), block(kBlock);
         switch (c.n_iter) {
-#define BHW_CASE(N) case N: hipLaunchKernelGGL(k_table_build_plain<N>, grid, block, 0, st, c, entries, (int2 *)d_table); break;
+#define BHW_CASE(N) case N: BHW_LAUNCH(k_table_build_plain<N>, grid, block, 0, st, c, entries, (int2 *)d_table); break;
             BHW_CASE(7) BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14)
             BHW_CASE(15) BHW_CASE(16) BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20) BHW_CASE(21) BHW_CASE(22)
             BHW_CASE(23) BHW_CASE(24) BHW_CASE(25) BHW_CASE(26) BHW_CASE(27) BHW_CASE(28) BHW_CASE(29) BHW_CASE(30)
@@ -1313,6 +1342,7 @@ int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table
         plan.pad0 = 0;
         plan.tab_coarse = c.tab_coarse;
         plan.x0 = c.x0;
+        plan.check_flag = c.tab_check;
         const unsigned groups = entries >> 6;
         plan.groups_per_wg = groups >= 64u * 1024u ? 64u : groups >= 16u * 1024u ? 16u : 4u;
         plan.pad = 0;
@@ -1321,7 +1351,7 @@ int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table
         // therefore at least 21 rotations: the VHDL model at PW == W runs W - 1 of them) from 21 rotations on
         const int fmt = c.tab_dlog == 0 ? 0 : c.tab_dlog == kPackLog ? 1 : 2;
         if (c.n_iter < 21 && fmt != 0) return (int)hipErrorInvalidValue;
-#define BHW_LAUNCH_BUILD(N, F) hipLaunchKernelGGL((k_table_build_shared<N, F>), grid, block, 0, st, plan, (void *)d_table)
+#define BHW_LAUNCH_BUILD(N, F) BHW_LAUNCH((k_table_build_shared<N, F>), grid, block, 0, st, plan, (void *)d_table)
 #define BHW_CASE(N) case N: BHW_LAUNCH_BUILD(N, 0); break;
 #define BHW_CASE_T(N) case N: if (fmt == 0) BHW_LAUNCH_BUILD(N, 0); else if (fmt == 1) BHW_LAUNCH_BUILD(N, 1); else BHW_LAUNCH_BUILD(N, 2); break;
         switch (c.n_iter) {
@@ -1337,8 +1367,8 @@ int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table
         return finish(hipSuccess);
     }
     if (c.tab_dlog > kPackLog) return (int)hipErrorInvalidValue;        // residual records come from the shared-prefix kernel only
-    if (c.wide) hipLaunchKernelGGL(k_table_build<int64_t>, dim3(grid_for(entries)), dim3(kBlock), 0, st, c, entries, (void *)d_table);
-    else        hipLaunchKernelGGL(k_table_build<int32_t>, dim3(grid_for(entries)), dim3(kBlock), 0, st, c, entries, (void *)d_table);
+    if (c.wide) BHW_LAUNCH(k_table_build<int64_t>, dim3(grid_for(entries)), dim3(kBlock), 0, st, c, entries, (void *)d_table);
+    else        BHW_LAUNCH(k_table_build<int32_t>, dim3(grid_for(entries)), dim3(kBlock), 0, st, c, entries, (void *)d_table);
     return finish(hipSuccess);
 }
 
@@ -1348,7 +1378,7 @@ int bhwk_table_combine(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCf
     if (!count) return 0;
     BHW_SET_DEVICE(l);
     hipStream_t st = (hipStream_t)l.stream;
-    hipLaunchKernelGGL(k_table_combine, dim3(grid_for(count)), dim3(kBlock), 0, st, c, w, (const void *)d_table, n0, count, d_out);
+    BHW_LAUNCH(k_table_combine, dim3(grid_for(count)), dim3(kBlock), 0, st, c, w, (const void *)d_table, n0, count, d_out);
     return finish(hipSuccess);
 }
 
@@ -1362,9 +1392,9 @@ int bhwk_table_combine_fold(const BhwLaunch &l, const BhwCordicCfg &c, const Bhw
         const dim3 grid(grid_for(quarter)), block(kBlock);
 #define BHW_FOLD_NT(NT)                                                                                                   \
         do {                                                                                                              \
-            if (mode == 0)      hipLaunchKernelGGL((k_table_combine_fold_t<NT, 0>), grid, block, 0, st, c, w, (const void *)d_table, d_out); \
-            else if (mode == 1) hipLaunchKernelGGL((k_table_combine_fold_t<NT, 1>), grid, block, 0, st, c, w, (const void *)d_table, d_out); \
-            else                hipLaunchKernelGGL((k_table_combine_fold_t<NT, 2>), grid, block, 0, st, c, w, (const void *)d_table, d_out); \
+            if (mode == 0)      BHW_LAUNCH((k_table_combine_fold_t<NT, 0>), grid, block, 0, st, c, w, (const void *)d_table, d_out); \
+            else if (mode == 1) BHW_LAUNCH((k_table_combine_fold_t<NT, 1>), grid, block, 0, st, c, w, (const void *)d_table, d_out); \
+            else                BHW_LAUNCH((k_table_combine_fold_t<NT, 2>), grid, block, 0, st, c, w, (const void *)d_table, d_out); \
         } while (0)
         switch (w.n_terms) {
         case 2: BHW_FOLD_NT(2); return finish(hipSuccess);
@@ -1376,7 +1406,7 @@ int bhwk_table_combine_fold(const BhwLaunch &l, const BhwCordicCfg &c, const Bhw
         }
 #undef BHW_FOLD_NT
     }
-    hipLaunchKernelGGL(k_table_combine_fold, dim3(grid_for(quarter)), dim3(kBlock), 0, st, c, w, (const void *)d_table, d_out);
+    BHW_LAUNCH(k_table_combine_fold, dim3(grid_for(quarter)), dim3(kBlock), 0, st, c, w, (const void *)d_table, d_out);
     return finish(hipSuccess);
 }
 
@@ -1435,9 +1465,9 @@ int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const Bhw
     const dim3 grid(tp.n_tiles), block(kTileThreads);
 #define BHW_LAUNCH_TILE_M(NB, M)                                                                                         \
     do {                                                                                                                 \
-        if (c.tab_dlog == 0)             hipLaunchKernelGGL((k_table_combine_tile<NB, M, 0>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
-        else if (c.tab_dlog == kPackLog) hipLaunchKernelGGL((k_table_combine_tile<NB, M, 1>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
-        else                             hipLaunchKernelGGL((k_table_combine_tile<NB, M, 2>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
+        if (c.tab_dlog == 0)             BHW_LAUNCH((k_table_combine_tile<NB, M, 0>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
+        else if (c.tab_dlog == kPackLog) BHW_LAUNCH((k_table_combine_tile<NB, M, 1>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
+        else                             BHW_LAUNCH((k_table_combine_tile<NB, M, 2>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
     } while (0)
 #define BHW_LAUNCH_TILE(NB)                                                                                              \
     do {                                                                                                                 \
@@ -1457,7 +1487,7 @@ int bhwk_taylor_window(const BhwLaunch &l, const BhwTaylorCfg &t, const BhwWinCf
 {
     if (!count) return 0;
     BHW_SET_DEVICE(l);
-    hipLaunchKernelGGL(k_taylor_window, dim3(grid_for(count)), dim3(kBlock), 0, (hipStream_t)l.stream, t, w, n0, count, d_out);
+    BHW_LAUNCH(k_taylor_window, dim3(grid_for(count)), dim3(kBlock), 0, (hipStream_t)l.stream, t, w, n0, count, d_out);
     return finish(hipSuccess);
 }
 
@@ -1477,8 +1507,8 @@ int bhwk_taylor_window_fold(const BhwLaunch &l, const BhwTaylorCfg &t, const Bhw
     hipStream_t st = (hipStream_t)l.stream;
 #define BHW_TAYLOR_FOLD(ARITH, COMBINE, NT)                                                                         \
     do {                                                                                                            \
-        if (fast) hipLaunchKernelGGL((k_taylor_window_fold<ARITH, COMBINE, NT, true>), grid, dim3(kBlock), 0, st, t, w, d_out);  \
-        else      hipLaunchKernelGGL((k_taylor_window_fold<(ARITH == 2 ? 0 : ARITH), COMBINE, NT, false>), grid, dim3(kBlock), 0, st, t, w, d_out); \
+        if (fast) BHW_LAUNCH((k_taylor_window_fold<ARITH, COMBINE, NT, true>), grid, dim3(kBlock), 0, st, t, w, d_out);  \
+        else      BHW_LAUNCH((k_taylor_window_fold<(ARITH == 2 ? 0 : ARITH), COMBINE, NT, false>), grid, dim3(kBlock), 0, st, t, w, d_out); \
     } while (0)
     const bool vhdl = w.combine == BHW_COMBINE_VHDL;
     // every generator in use (PHASE_WIDTH - v, v <= vmax) on the 1st-order-correction path, ROM in LDS
@@ -1599,7 +1629,7 @@ int bhwk_sincos_prerot(const BhwLaunch &l, const BhwPrerotCfg &c, uint64_t theta
     const dim3 grid(grid_for(count)), block(kBlock);
     hipStream_t st = (hipStream_t)l.stream;
     switch (c.dat_width) {                                              // DATA_WIDTH stages, unrolled
-#define BHW_CASE(N) case N: hipLaunchKernelGGL(k_sincos_prerot<N>, grid, block, 0, st, c, theta0, count, d_sin, d_cos); break;
+#define BHW_CASE(N) case N: BHW_LAUNCH(k_sincos_prerot<N>, grid, block, 0, st, c, theta0, count, d_sin, d_cos); break;
         BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14) BHW_CASE(15) BHW_CASE(16)
         BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20) BHW_CASE(21) BHW_CASE(22) BHW_CASE(23) BHW_CASE(24)
         BHW_CASE(25) BHW_CASE(26) BHW_CASE(27) BHW_CASE(28) BHW_CASE(29) BHW_CASE(30) BHW_CASE(31) BHW_CASE(32)
@@ -1613,7 +1643,7 @@ int bhwk_atan2(const BhwLaunch &l, const BhwAtan2Cfg &c, uint64_t count, const i
 {
     if (!count) return 0;
     BHW_SET_DEVICE(l);
-    hipLaunchKernelGGL(k_atan2, dim3(grid_for(count)), dim3(kBlock), 0, (hipStream_t)l.stream, c, count, d_x, d_y, d_phi);
+    BHW_LAUNCH(k_atan2, dim3(grid_for(count)), dim3(kBlock), 0, (hipStream_t)l.stream, c, count, d_x, d_y, d_phi);
     return finish(hipSuccess);
 }
 
@@ -1621,6 +1651,6 @@ int bhwk_taylor_sincos(const BhwLaunch &l, const BhwTaylorCfg &t, uint64_t theta
 {
     if (!count) return 0;
     BHW_SET_DEVICE(l);
-    hipLaunchKernelGGL(k_taylor_sincos, dim3(grid_for(count)), dim3(kBlock), 0, (hipStream_t)l.stream, t, theta0, count, d_sin, d_cos);
+    BHW_LAUNCH(k_taylor_sincos, dim3(grid_for(count)), dim3(kBlock), 0, (hipStream_t)l.stream, t, theta0, count, d_sin, d_cos);
     return finish(hipSuccess);
 }

@@ -40,24 +40,50 @@ def shard_range(total, rank, world_size):
     return n0, base + (1 if rank < rem else 0)
 
 
-def generate(params, n0, count, *, device=None, out=None, algo=B.ALGO_AUTO, workspace=None, event_after_build=None):
+def _check_out(torch, out, need, what="out"):
+    """An output tensor handed to the kernels: int32, on a GPU, contiguous, large enough."""
+    if out.dtype != torch.int32 or not out.is_cuda or not out.is_contiguous() or out.numel() < need:
+        raise ValueError(f"{what} must be a contiguous int32 CUDA tensor with at least {need} elements")
+    return out.device.index
+
+
+def _exec(algo, workspace, event_after_build=None, table_format=B.TABLE_BEST):
+    ex = B.BhwExec()
+    ex.struct_size = ctypes.sizeof(B.BhwExec)
+    ex.algo = algo
+    ex.table_format = table_format
+    if workspace is not None:
+        if not workspace.is_cuda or not workspace.is_contiguous():
+            raise ValueError("workspace must be a contiguous CUDA tensor")
+        ex.workspace = workspace.data_ptr()
+        ex.workspace_bytes = workspace.numel() * workspace.element_size()
+    if event_after_build is not None:      # a torch.cuda.Event that has been recorded once (its handle exists)
+        ex.event_after_build = event_after_build.cuda_event
+    return ex
+
+
+def prepare(params, *, device=None):
+    """Every lazy step of later calls with `params` on the current stream, done now (bhw_prepare_device): Taylor ROM upload,
+    library scratch, one-off verification of the packed table formats.  Needed before capturing calls into a HIP graph
+    without a caller workspace; otherwise optional."""
+    torch = _torch()
+    dev = _dev_index(torch, device)
+    with torch.cuda.device(dev):
+        B.check(B.lib().bhw_prepare_device(ctypes.byref(params), dev, _stream_ptr(torch, dev)))
+
+
+def generate(params, n0, count, *, device=None, out=None, algo=B.ALGO_AUTO, workspace=None, event_after_build=None,
+             table_format=B.TABLE_BEST):
     """count coefficients starting at stream index n0 as an int32 CUDA tensor (bhw_generate_device)."""
     torch = _torch()
     dev = _dev_index(torch, device)
     if out is None:
         out = torch.empty(int(count), dtype=torch.int32, device=f"cuda:{dev}")
     else:
-        if out.dtype != torch.int32 or not out.is_cuda or not out.is_contiguous() or out.numel() < count:
-            raise ValueError("out must be a contiguous int32 CUDA tensor with at least `count` elements")
-        dev = out.device.index
-    ex = B.BhwExec()
-    ex.struct_size = ctypes.sizeof(B.BhwExec)
-    ex.algo = algo
-    if workspace is not None:
-        ex.workspace = workspace.data_ptr()
-        ex.workspace_bytes = workspace.numel() * workspace.element_size()
-    if event_after_build is not None:      # a torch.cuda.Event that has been recorded once (its handle exists)
-        ex.event_after_build = event_after_build.cuda_event
+        dev = _check_out(torch, out, int(count))
+    if workspace is not None and workspace.device.index != dev:
+        raise ValueError("workspace must live on the output's device")
+    ex = _exec(algo, workspace, event_after_build, table_format)
     with torch.cuda.device(dev):
         B.check(B.lib().bhw_generate_device_ex(ctypes.byref(params), dev, _stream_ptr(torch, dev), int(n0), int(count),
                                                 ctypes.c_void_p(out.data_ptr()), ctypes.byref(ex)))
@@ -73,6 +99,8 @@ def apply(params, x, *, n0=0, shift=None, out=None):
     dev = x.device.index
     if out is None:
         out = torch.empty_like(x)
+    elif _check_out(torch, out, x.numel()) != dev:
+        raise ValueError("out must live on x's device")
     if shift is None:
         shift = params.dat_width - 1
     with torch.cuda.device(dev):
@@ -88,7 +116,7 @@ def generate_batched(params, frames, *, device=None, out=None):
     n = 1 << params.phi_width
     if out is None:
         out = torch.empty((int(frames), n), dtype=torch.int32, device=f"cuda:{dev}")
-    dev = out.device.index
+    dev = _check_out(torch, out, int(frames) * n)
     with torch.cuda.device(dev):
         B.check(B.lib().bhw_generate_batched_device(ctypes.byref(params), dev, _stream_ptr(torch, dev), int(frames),
                                                      ctypes.c_void_p(out.data_ptr())))

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BHW_ABI_VERSION 1u
+#define BHW_ABI_VERSION 2u
 
 /* CORDIC bit-model (the reference holds three that are not bit-identical). */
 enum {
@@ -79,21 +79,33 @@ typedef struct bhw_params {
     uint32_t sin_type;     /* BHW_SIN_*                      SIN_TYPE                     */
     uint32_t win_type;     /* BHW_WIN_* (informational; n_terms + aa define the window)   */
     uint32_t n_terms;      /* 2,3,4,5,7                      WIN_TYPE                     */
-    uint32_t phi_width;    /* 4..26, N = 2^phi_width         PHI_WIDTH                    */
+    uint32_t phi_width;    /* 4..30, N = 2^phi_width         PHI_WIDTH (the reference documents up to 26,
+                              README.md:2; 27..30 are the same arithmetic on a longer counter)          */
     uint32_t dat_width;    /* 8..32                          DAT_WIDTH                    */
     uint32_t precision;    /* model VHDL only, 1..7          cordic_dds PRECISION         */
     uint32_t lut_size;     /* Taylor only                    LUT_SIZE                     */
     int32_t  aa[7];        /* AA0..AA6, caller-scaled integer weights                     */
 } bhw_params;
 
+/* Storage format of the first-quadrant (c, s) table of BHW_ALGO_TABLE (results are bit-identical across formats;
+ * a format that does not apply to a configuration falls back to the next wider one). */
+enum {
+    BHW_TABLE_BEST     = 0, /* narrowest format that is exact for the configuration                 */
+    BHW_TABLE_PLAIN    = 1, /* int2 (c, s) per entry, 8 bytes                                       */
+    BHW_TABLE_DELTA16  = 2, /* at most: 4 bytes per entry (int16 differences to a 64-entry block head) */
+    BHW_TABLE_RESIDUAL = 3  /* at most: 2 bytes per entry against a linear predictor                 */
+};
+
 /* Optional execution controls for the *_ex entry points. */
 typedef struct bhw_exec {
-    uint32_t struct_size;     /* sizeof(bhw_exec)                                          */
+    uint32_t struct_size;     /* sizeof(bhw_exec) (the 32-byte ABI-1 layout without table_format is accepted) */
     uint32_t algo;            /* BHW_ALGO_*                                                */
     void    *workspace;       /* device scratch (NULL: library-owned scratch of this stream) */
     uint64_t workspace_bytes;
     void    *event_after_build; /* optional hipEvent_t recorded on the stream between the table build and the
                                    combine pass (per-kernel timing for profilers); NULL = none      */
+    uint32_t table_format;    /* BHW_TABLE_* (diagnostics / A-B runs; 0 = best)            */
+    uint32_t reserved;        /* must be 0                                                 */
 } bhw_exec;
 
 uint32_t    bhw_abi_version(void);
@@ -125,6 +137,15 @@ int bhw_generate_device_ex(const bhw_params *p, int device, void *hip_stream,
                            uint64_t n0, uint64_t count, int32_t *d_out, const bhw_exec *ex);
 /* Device scratch the given call would need with `algo` (0 for the direct strategy). */
 uint64_t bhw_workspace_bytes(const bhw_params *p, uint64_t n0, uint64_t count, uint32_t algo);
+
+/* Does every lazy step of later calls with `p` on (device, hip_stream) now: uploads the Taylor quarter-wave ROM
+ * (taylor_sincos.vhd:91-111 builds it at elaboration), allocates the library-owned table scratch of this stream, and verifies
+ * once, on the device, that the packed table formats are exact for this (model, phi_width, dat_width, precision) -- a property
+ * of the configuration, not of the weights.  Synchronous.  After it, bhw_generate_* / bhw_apply_* / bhw_sincos_* calls with
+ * these widths neither allocate nor synchronise, so they can be captured into a HIP graph.  Without it the first call does
+ * the same work inline (one synchronisation); during stream capture an unprepared Taylor call fails with BHW_ERR_HIP and an
+ * unprepared table call uses the plain table format. */
+int bhw_prepare_device(const bhw_params *p, int device, void *hip_stream);
 
 /* Fused apply (the step after the path in every consumer -- the window multiplies the samples in
  * front of an FFT).  d_y[i] = (d_x[i] * w[n0+i]) >> shift with the exact 64-bit product (as int_multNxN_dsp48,
@@ -168,7 +189,13 @@ int bhw_atan2_device(const bhw_atan2_params *p, int device, void *hip_stream, ui
 int bhw_atan2_to_host(const bhw_atan2_params *p, int device, uint64_t count,
                       const int32_t *h_x, const int32_t *h_y, int32_t *h_phi);
 
-/* Releases the library-owned per-device scratch. */
+/* Threading: every entry point may be called from any host thread.  Calls that use the library-owned scratch of one
+ * (device, stream) are serialised against each other for the duration of their launches (the table is rebuilt per call);
+ * callers that pass their own bhw_exec.workspace must not share one workspace between concurrent calls.  The calling
+ * thread's current HIP device is restored before every entry point returns, and no entry point reads or clears the
+ * thread's hipGetLastError() state.
+ *
+ * Releases the library-owned per-device scratch. */
 int bhw_release_device(int device);
 
 #ifdef __cplusplus

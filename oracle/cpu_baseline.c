@@ -59,6 +59,45 @@ static void *port_worker(void *arg)
     return NULL;
 }
 
+typedef struct {
+    const bhwo_params *p;
+    uint64_t theta0, count;
+    int32_t *s, *c;
+} sc_job_t;
+
+static void *sincos_worker(void *arg)
+{
+    sc_job_t *j = (sc_job_t *)arg;
+    bhwo_sincos(j->p, j->theta0, j->count, j->s, j->c);
+    return NULL;
+}
+
+/* bhwo_sincos over host threads (contiguous phase shards): whole-quadrant sweeps in tests.  Returns 0 / -1. */
+int bhw_cpu_sincos_mt(const bhwo_params *p, uint64_t theta0, uint64_t count, int threads, int32_t *out_sin, int32_t *out_cos)
+{
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    int32_t probe_s, probe_c;
+    if (bhwo_sincos(p, theta0, 1, &probe_s, &probe_c)) return -1;
+    sc_job_t *jobs = (sc_job_t *)calloc((size_t)threads, sizeof(sc_job_t));
+    pthread_t *tid = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    const uint64_t base = count / (uint64_t)threads, rem = count % (uint64_t)threads;
+    uint64_t off = 0;
+    for (int t = 0; t < threads; ++t) {
+        jobs[t].p = p;
+        jobs[t].theta0 = theta0 + off;
+        jobs[t].count = base + ((uint64_t)t < rem ? 1 : 0);
+        jobs[t].s = out_sin + off;
+        jobs[t].c = out_cos + off;
+        off += jobs[t].count;
+        pthread_create(&tid[t], NULL, sincos_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; ++t) pthread_join(tid[t], NULL);
+    free(jobs);
+    free(tid);
+    return 0;
+}
+
 static double now(void)
 {
     struct timespec ts;

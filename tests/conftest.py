@@ -15,11 +15,12 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session", autouse=True)
 def _built():
-    """Build the C-ABI library and the oracle when they are missing (CPU container: hipcc cross-compiles)."""
+    """Build the C-ABI library and the oracle when they are missing or were built from other sources (a content hash of the
+    sources sits next to each library, so a stale library is never tested and an up-to-date one costs nothing; hipcc
+    cross-compiles in the CPU container, the GPU box uses the snapshot's prebuilt files)."""
     from blackman_harris_win_amd import _build
-    if not os.path.exists(_build.LIB):
-        _build.build_library()
-    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+    _build.build_library()
+    if _build.oracle_stale():
         _build.build_oracle()
 
 

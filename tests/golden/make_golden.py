@@ -59,7 +59,12 @@ def c3_shard(g, model=O.MODEL_HLS):
 
 
 def c3_shard_cpp(g):
-    return c3_shard(g, O.MODEL_CPP)
+    """Shard g of the headline window with model A cosines, evaluated by the reference's own compiled cordic()
+    (oracle/_ref/libref_cordic_26_32.so) in the cosine-sum of win_function.cpp:361-375 -- no oracle restatement of the CORDIC."""
+    a = O.reference_window(O.oparams(7, 26, 32, model=O.MODEL_CPP), g << 23, 1 << 23, threads=1)
+    st = stats(a)
+    st["strided_1024"] = [int(v) for v in a[:: (1 << 23) // 1024][:1024]]
+    return g, st
 
 
 def main():
@@ -166,9 +171,13 @@ def main():
     with Pool(8) as pool:
         shards_cpp = dict(pool.map(c3_shard_cpp, range(8)))
     pc = O.oparams(7, 26, 32, model=O.MODEL_CPP)
-    E["C3cpp_bh7_26_32"] = {"source": "oracle", "note": "BH-7 2^26/32-bit with model CPP cosines (oracle pinned bit-for-bit to the "
-                            "reference's cordic() via oracle/_ref) in the HLS cosine-sum rule; per-shard checksums",
+    E["C3cpp_bh7_26_32"] = {"source": "reference", "note": "BH-7 2^26/32-bit: six calls of the reference's compiled cordic() "
+                            "(oracle/_ref, cpp/cordic_sincos.cpp built at PHASE_WIDTH 26 / DATA_WIDTH 32) per coefficient in the "
+                            "cosine-sum of hls/windows/win_function.cpp:361-375; per-shard checksums",
                             "params": pdict(pc), "shards": [shards_cpp[g] for g in range(8)]}
+    # the oracle's restatement of model A gives the same shards (cross-check, one shard)
+    chk = O.generate_mt(pc, 5 << 23, 1 << 23)
+    assert md5(chk) == shards_cpp[5]["md5"], "oracle model A != reference-compiled window"
 
     # ---- oracle-only vectors: no runnable reference (parity unpinned) or derived configurations --------
     def oracle_only(name, p, n0, count, keep=True, note="parity unpinned: restated from the VHDL, no simulator here"):

@@ -89,17 +89,52 @@ _cb = None
 
 def generate_mt(p, n0, count, threads=None):
     """bhwo_generate over host threads (oracle/libcpubaseline.so, the same restatement): for whole windows of 2^22 and up."""
+    if threads is None:
+        threads = host_threads()
+    out = np.empty(int(count), np.int32)
+    if _cpubaseline().bhw_cpu_baseline(None, ctypes.byref(p), int(n0), int(count), threads, out.ctypes.data) < 0:
+        raise ValueError("oracle rejected the parameters")
+    return out
+
+
+def _cpubaseline():
     global _cb
     if _cb is None:
         _cb = ctypes.CDLL(os.path.join(os.path.dirname(ORACLE_SO), "libcpubaseline.so"))
         _cb.bhw_cpu_baseline.restype = ctypes.c_double
         _cb.bhw_cpu_baseline.argtypes = [ctypes.c_char_p, ctypes.POINTER(OParams), ctypes.c_uint64, ctypes.c_uint64,
                                          ctypes.c_int, ctypes.c_void_p]
-    if threads is None:
-        threads = min(16, len(os.sched_getaffinity(0)))
-    out = np.empty(int(count), np.int32)
-    if _cb.bhw_cpu_baseline(None, ctypes.byref(p), int(n0), int(count), threads, out.ctypes.data) < 0:
+        _cb.bhw_cpu_sincos_mt.argtypes = [ctypes.POINTER(OParams), ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int,
+                                          ctypes.c_void_p, ctypes.c_void_p]
+    return _cb
+
+
+def host_threads(cap=16):
+    return max(1, min(cap, len(os.sched_getaffinity(0))))
+
+
+def sincos_mt(p, theta0, count, threads=None):
+    """bhwo_sincos over host threads: (sin, cos) for whole quadrants of 2^22 phases and up."""
+    s = np.empty(int(count), np.int32)
+    c = np.empty(int(count), np.int32)
+    if _cpubaseline().bhw_cpu_sincos_mt(ctypes.byref(p), int(theta0), int(count), threads or host_threads(),
+                                        s.ctypes.data, c.ctypes.data):
         raise ValueError("oracle rejected the parameters")
+    return s, c
+
+
+def reference_window(p, n0, count, threads=None):
+    """The window as the reference's own compiled code evaluates it (oracle/_ref): K-1 calls of cordic() of
+    cpp/cordic_sincos.cpp -- compiled from the reference source at (PHASE_WIDTH, DATA_WIDTH) = (p.phi_width, p.dat_width),
+    oracle/Makefile -- per coefficient, followed by the cosine-sum of hls/windows/win_function.cpp:361-375 (oracle/cpu_baseline.c
+    ref_worker).  No restatement of the CORDIC is involved.  Raises FileNotFoundError when that width pair was not built."""
+    lib = os.path.join(REF_DIR, f"libref_cordic_{p.phi_width}_{p.dat_width}.so")
+    if not os.path.exists(lib):
+        raise FileNotFoundError(lib)
+    out = np.empty(int(count), np.int32)
+    dt = _cpubaseline().bhw_cpu_baseline(lib.encode(), ctypes.byref(p), int(n0), int(count), threads or host_threads(), out.ctypes.data)
+    if dt < 0:
+        raise RuntimeError(f"bhw_cpu_baseline failed ({dt}) for {lib}")
     return out
 
 

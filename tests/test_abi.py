@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_loads_and_exports_every_declared_symbol():
     L = B.lib()
-    assert L.bhw_abi_version() == 1
+    assert L.bhw_abi_version() == 2
     header = open(os.path.join(ROOT, "include", "bhw.h")).read()
     declared = set(re.findall(r"\b(bhw_[a-z_0-9]+)\s*\(", header))
     assert declared == set(B.ABI_SYMBOLS)
@@ -24,7 +24,8 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     assert ctypes.sizeof(B.BhwParams) == 4 * 10 + 4 * 7
-    assert ctypes.sizeof(B.BhwExec) == 32
+    assert ctypes.sizeof(B.BhwExec) == 40          # ABI 2: + table_format, reserved (the 32-byte ABI-1 layout is still accepted)
+    assert B.BhwExec.table_format.offset == 32
 
 
 def test_strerror():

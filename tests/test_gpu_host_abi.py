@@ -1,0 +1,203 @@
+"""Host-side behaviour of the C ABI on a GPU (include/bhw.h "Threading", bhw_prepare_device, packed-format verification)."""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from blackman_harris_win_amd import binding as B
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def test_two_threads_same_stream_share_library_scratch_safely(torch):
+    """Two host threads, the same (device, stream), different windows, library-owned scratch: the launches of one call must
+    not interleave with the other's (A.build, B.build, A.combine would combine A from B's table), and a call that needs a larger
+    buffer must not free the one the other is about to launch with."""
+    import blackman_harris_win_amd as bhw
+    pa = B.make_params(7, 18, 32)
+    pb = B.make_params(5, 20, 24, model=B.MODEL_CPP)                  # larger table: forces a re-allocation of the shared slot
+    pc = B.make_params(4, 16, 30, model=B.MODEL_VHDL, combine=B.COMBINE_VHDL)
+    want = {id(p): O.generate_mt(O.from_bhw(p), 0, 1 << p.phi_width) for p in (pa, pb, pc)}
+    st = torch.cuda.Stream()
+    errors = []
+
+    def worker(p, rounds):
+        try:
+            with torch.cuda.stream(st):
+                for _ in range(rounds):
+                    out = bhw.generate(p, 0, 1 << p.phi_width, algo=B.ALGO_TABLE)
+                    st.synchronize()
+                    if not np.array_equal(out.cpu().numpy(), want[id(p)]):
+                        errors.append(("mismatch", p.n_terms, p.phi_width))
+                        return
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(p, 40)) for p in (pa, pb, pc)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    # the NULL-stream helper shares one slot between threads as well
+    host = [(ctypes.c_int32 * (1 << p.phi_width))() for p in (pa, pc)]
+
+    def to_host(p, buf):
+        for _ in range(10):
+            rc = B.lib().bhw_generate_to_host(ctypes.byref(p), 0, 0, 1 << p.phi_width, buf)
+            if rc != 0 or not np.array_equal(np.ctypeslib.as_array(buf), want[id(p)]):
+                errors.append(("to_host", rc))
+                return
+
+    threads = [threading.Thread(target=to_host, args=(p, b)) for p, b in zip((pa, pc), host)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
+def test_current_device_is_restored_and_errors_are_not_consumed(torch):
+    """The entry points leave the thread's current device alone and neither read nor clear its hipGetLastError() state."""
+    hip = ctypes.CDLL("libamdhip64.so")
+    cur = ctypes.c_int(-1)
+    assert hip.hipGetDevice(ctypes.byref(cur)) == 0
+    before = cur.value
+    p = B.make_params(4, 12, 24)
+    out = torch.empty(4096, dtype=torch.int32, device="cuda")
+    # leave an error behind on this thread (an invalid device ordinal), as another library might
+    assert hip.hipSetDevice(12345) != 0
+    assert B.lib().bhw_generate_device(ctypes.byref(p), 0, None, 0, 4096, ctypes.c_void_p(out.data_ptr())) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), O.generate(O.from_bhw(p), 0, 4096))
+    assert hip.hipGetDevice(ctypes.byref(cur)) == 0 and cur.value == before
+    assert hip.hipGetLastError() != 0          # still there: the call did not swallow it (and did not fail because of it)
+    assert hip.hipGetLastError() == 0
+
+
+def test_prepare_then_graph_capture_without_workspace(torch):
+    """After bhw_prepare_device a table call with library scratch and a Taylor call neither allocate nor synchronise: both can
+    be captured into a HIP graph; unprepared, the Taylor call refuses inside a capture instead of breaking it."""
+    import blackman_harris_win_amd as bhw
+    st = torch.cuda.Stream()
+    pt = B.make_params(7, 22, 30)
+    py = B.make_params(3, 16, 27, combine=B.COMBINE_VHDL, sin_type=B.SIN_TAYLOR, lut_size=7)   # a ROM no other test uploads
+    want_t = O.generate_mt(O.from_bhw(pt), 0, 1 << 22)
+    with torch.cuda.stream(st):
+        out_t = torch.zeros(1 << 22, dtype=torch.int32, device="cuda")
+        out_y = torch.zeros(1 << 16, dtype=torch.int32, device="cuda")
+        st.synchronize()
+        g_bad = torch.cuda.CUDAGraph()
+        with pytest.raises(B.BhwError) as ei:
+            with torch.cuda.graph(g_bad, stream=st):
+                bhw.generate(py, 0, 1 << 16, out=out_y)
+        assert ei.value.code == -3 and "bhw_prepare_device" in ei.value.detail
+        del g_bad
+        bhw.prepare(pt)
+        bhw.prepare(py)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st):
+            bhw.generate(pt, 0, 1 << 22, out=out_t)
+            bhw.generate(py, 0, 1 << 16, out=out_y)
+        for _ in range(2):
+            out_t.zero_()
+            out_y.zero_()
+            graph.replay()
+            st.synchronize()
+            assert np.array_equal(out_t.cpu().numpy(), want_t)
+            assert np.array_equal(out_y.cpu().numpy(), O.generate(O.from_bhw(py), 0, 1 << 16))
+
+
+def _dbg():
+    L = B.lib()
+    P = ctypes.POINTER(B.BhwParams)
+    L.bhw_dbg_check_table_format.argtypes = [P, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p,
+                                             ctypes.POINTER(ctypes.c_uint32)]
+    L.bhw_dbg_table_format_verdict.argtypes = [P, ctypes.c_uint32, ctypes.c_int]
+    L.bhw_dbg_table_format_info.argtypes = [P, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+    return L
+
+
+def test_packed_format_overflow_is_detected_on_the_device(torch):
+    """The build kernels' check word: clear for the formats the library would choose, set when a format is forced onto a
+    configuration it cannot hold (delta16 at W - PW = 10: the drift over a 64-entry block exceeds int16; residual cells of
+    2^9 entries at 2^22 / 32 bits: the curvature alone exceeds int8)."""
+    L = _dbg()
+    flag = ctypes.c_uint32(7)
+    for win, pw, w, model, dlog, expect in [(7, 26, 32, B.MODEL_HLS, 9, 0), (7, 26, 32, B.MODEL_CPP, 9, 0), (7, 24, 32, B.MODEL_HLS, 6, 0),
+                                            (7, 22, 32, B.MODEL_HLS, 6, 1), (7, 22, 32, B.MODEL_HLS, 9, 1), (4, 22, 24, B.MODEL_VHDL, 9, 0)]:
+        p = B.make_params(win, pw, w, model=model)
+        ws = torch.empty(B.lib().bhw_workspace_bytes(ctypes.byref(p), 0, 1 << pw, B.ALGO_TABLE), dtype=torch.uint8, device="cuda")
+        assert L.bhw_dbg_check_table_format(ctypes.byref(p), 0, None, dlog, ctypes.c_void_p(ws.data_ptr()), ctypes.byref(flag)) == 0
+        assert flag.value == expect, (win, pw, w, model, dlog)
+
+
+def test_overflowing_format_falls_back_and_stays_exact(torch):
+    """A configuration whose packed-format verdict is 'overflows' is generated through the next wider format, bit-exactly."""
+    import blackman_harris_win_amd as bhw
+    L = _dbg()
+    p = B.make_params(5, 22, 26, model=B.MODEL_VHDL, precision=2)         # a configuration no other test touches
+    d, ok16 = ctypes.c_uint32(), ctypes.c_uint32()
+    assert L.bhw_dbg_table_format_info(ctypes.byref(p), ctypes.byref(d), ctypes.byref(ok16)) == 0
+    assert d.value >= 7 and ok16.value == 1
+    assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), d.value, 0) == 0              # unknown so far
+    want = O.generate_mt(O.from_bhw(p), 0, 1 << 22)
+    assert np.array_equal(bhw.generate(p, 0, 1 << 22, algo=B.ALGO_TABLE).cpu().numpy(), want)
+    assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), d.value, 0) == 1              # verified exact on first use
+    assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), d.value, 2) == 2              # pretend it overflowed
+    assert np.array_equal(bhw.generate(p, 0, 1 << 22, algo=B.ALGO_TABLE).cpu().numpy(), want)   # delta16 now
+    assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), 6, 0) == 1
+    assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), 6, 2) == 2
+    assert np.array_equal(bhw.generate(p, 0, 1 << 22, algo=B.ALGO_TABLE).cpu().numpy(), want)   # plain now
+    assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), d.value, 1) == 1
+    assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), 6, 1) == 1
+
+
+def test_out_tensors_are_validated(torch):
+    import blackman_harris_win_amd as bhw
+    p = B.make_params(4, 10, 24)
+    x = torch.zeros(1024, dtype=torch.int32, device="cuda")
+    with pytest.raises(ValueError):
+        bhw.apply(p, x, out=torch.zeros(1000, dtype=torch.int32, device="cuda"))          # too short
+    with pytest.raises(ValueError):
+        bhw.apply(p, x, out=torch.zeros(2048, dtype=torch.int32, device="cuda")[::2])     # strided
+    with pytest.raises(ValueError):
+        bhw.generate_batched(p, 4, out=torch.zeros(4 * 1024, dtype=torch.int64, device="cuda"))
+    with pytest.raises(ValueError):
+        bhw.generate_batched(p, 4, out=torch.zeros(3 * 1024, dtype=torch.int32, device="cuda"))
+    with pytest.raises(ValueError):
+        bhw.generate(p, 0, 1024, out=torch.zeros(1024, dtype=torch.int32))                # not on the GPU
+
+
+@pytest.mark.parametrize("pw", [28, 30])
+def test_long_windows_27_to_30_bits(torch, pw):
+    """phi_width above the reference's documented 26 (README.md:2): the same arithmetic on a longer counter.  Whole 2^28 /
+    2^30 windows through the tile path, against DIRECT slices (device-side comparison) and the oracle on sampled indices."""
+    import blackman_harris_win_amd as bhw
+    w = 32
+    p = B.make_params(7, pw, w)
+    n = 1 << pw
+    full = bhw.generate(p, 0, n, algo=B.ALGO_TABLE)
+    rng = np.random.default_rng(pw)
+    starts = [0, n // 8 - 3000, n // 4 - 3000, n // 2 - 3000, 3 * (n // 4) - 3000, n - 6000] + [int(v) for v in rng.integers(0, n - 6000, 6)]
+    for s0 in starts:
+        sl = bhw.generate(p, s0, 6000, algo=B.ALGO_DIRECT)
+        assert bool((sl == full[s0:s0 + 6000]).all()), s0
+    idx = np.unique(np.concatenate([rng.integers(0, n, 600), [0, 1, n // 2, n // 2 - 1, n - 1]]))
+    po = O.from_bhw(p)
+    want = np.array([O.generate(po, int(i), 1)[0] for i in idx], dtype=np.int32)
+    got = full[torch.as_tensor(idx, device="cuda")].cpu().numpy()
+    assert np.array_equal(got, want)
+    # quadrant fold as a size-independent property: the window sum and its extremes sit where they must
+    assert int(full[n // 2]) == int(full.max())
+    del full
+    B.lib().bhw_release_device(0)

@@ -528,10 +528,11 @@ def test_c3_full_64m(torch, golden):
     for n, v in e["sparse"].items():
         assert int(full[int(n)]) == v
     # C5 sharding: each device-sized shard generated on its own (both strategies) equals the slice of the whole
-    for g in (0, 3, 5):
-        for algo in ALGOS:
+    for g in range(8):
+        for algo in ALGOS + [B.ALGO_AUTO]:
             sh = bhw.generate(p, g << 23, 1 << 23, algo=algo)
             assert bool((sh == full[g << 23:(g + 1) << 23]).all()), (g, algo)
+            assert _md5(sh.cpu().numpy()) == e["shards"][g]["md5"]
     # periodicity: the stream index wraps modulo N
     tail = bhw.generate(p, (1 << 26) - 1000, 2000, algo=B.ALGO_DIRECT)
     assert bool((tail[:1000] == full[-1000:]).all()) and bool((tail[1000:] == full[:1000]).all())
@@ -540,22 +541,16 @@ def test_c3_full_64m(torch, golden):
 
 def test_packed_table_is_exact(torch, golden):
     """The packed tables -- "residual" (2 bytes per entry against a linear predictor) and "delta16" (int16 differences to the first
-    entry of each 64-entry block) -- must give the same coefficients as the plain int2 table (BHW_TABLE_PACK = 2 / 1 / 0)."""
-    import subprocess, sys
-    code = (
-        "import hashlib, sys; sys.path.insert(0, %r)\n"
-        "import blackman_harris_win_amd as bhw\n"
-        "from blackman_harris_win_amd import binding as B\n"
-        "for win, pw, w, model in ((7, 26, 32, 0), (7, 24, 32, 1), (4, 22, 24, 2), (5, 23, 29, 0), (7, 22, 28, 2), (3, 22, 30, 0), (7, 22, 32, 0), (7, 25, 26, 1)):\n"
-        "    p = B.make_params(win, pw, w, model=model)\n"
-        "    a = bhw.generate(p, 12345, (1 << pw) + 99999, algo=B.ALGO_TABLE).cpu().numpy()\n"
-        "    print(hashlib.md5(a.tobytes()).hexdigest())\n" % ROOT)
-    outs = []
-    for flag in ("0", "1", "2"):
-        env = dict(os.environ, BHW_TABLE_PACK=flag)
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, check=True)
-        outs.append(r.stdout.split())
-    assert outs[0] == outs[1] == outs[2] and len(outs[0]) == 8
+    entry of each 64-entry block) -- must give the same coefficients as the plain int2 table (bhw_exec.table_format)."""
+    import blackman_harris_win_amd as bhw
+    for win, pw, w, model in ((7, 26, 32, 0), (7, 24, 32, 1), (4, 22, 24, 2), (5, 23, 29, 0), (7, 22, 28, 2), (3, 22, 30, 0),
+                              (7, 22, 32, 0), (7, 25, 26, 1)):
+        p = B.make_params(win, pw, w, model=model)
+        outs = [bhw.generate(p, 12345, (1 << pw) + 99999, algo=B.ALGO_TABLE, table_format=f)
+                for f in (B.TABLE_PLAIN, B.TABLE_DELTA16, B.TABLE_RESIDUAL, B.TABLE_BEST)]
+        for o in outs[1:]:
+            assert bool((o == outs[0]).all()), (win, pw, w, model)
+        del outs
 
 
 def test_c3_full_64m_model_cpp(torch, golden):
