@@ -10,12 +10,17 @@ One process per GPU.  A step = one pass of the hot path over one batch: 2^26 coe
 from the parameter set into a resident HBM buffer (no inputs; nothing cached between steps: the
 shared CORDIC table is rebuilt inside every step).  With N ranks the coefficient stream is sharded by
 contiguous index range -- rank r produces stream indices [r*2^26, (r+1)*2^26) -- with no data-path
-collective (weak scaling: fixed work per GPU).  Rank 0 prints ONE JSON line.
+collective (weak scaling: fixed work per GPU; the default, "scaling": "weak").
+`--scaling strong` is BASELINE config C5 instead: ONE 2^26 window over the N ranks, each producing its interleaved
+ownership part (bhw_generate_part_device) into a full-length buffer, still without a collective; value is then
+2^26 coefficients x steps / time.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -88,15 +93,52 @@ def cpu_baseline(target_seconds=12.0, max_threads=16):
             "matches_oracle": ok}
 
 
+def sources_sha16():
+    """sha256 prefix of the kernel + ABI sources: ties a committed PMC summary to the code it was measured on."""
+    h = hashlib.sha256()
+    for f in ("bhw_kernels.hip", "bhw_api.cpp", "bhw_internal.h"):
+        with open(os.path.join(ROOT, "blackman_harris_win_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic():
-    """HBM bytes per step from the committed rocprofv3 PMC passes of this same command (tools/gpu_pmc.sh ->
+    """(bytes, source): HBM bytes per step from the committed rocprofv3 PMC passes of this same command (tools/gpu_pmc.sh ->
     profiles/pmc_latest.json): 2 x FETCH_SIZE + WRITE_SIZE per kernel, summed over the kernels of one step (the gfx950
-    correction of MI355X_MICROARCH.md section HBM; WRITE_SIZE calibrated on the build kernel's known 8 B x 2^24)."""
+    correction of MI355X_MICROARCH.md section HBM; WRITE_SIZE calibrated on the build kernel's known bytes).  A citation of
+    an earlier profiling run, not a measurement of this run: the source record says which file, when, and on which source
+    hash; a summary taken on other sources is not quoted (bytes = None)."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
-            return float(json.load(f)["_step_hbm_bytes"])
+        with open(path) as f:
+            d = json.load(f)
     except Exception:
-        return None
+        return None, {"file": None, "note": "no committed PMC summary"}
+    meta = d.get("_meta", {})
+    src = {"file": "profiles/pmc_latest.json", "measured": meta.get("date"), "sources_sha16": meta.get("sources_sha16"),
+           "command": meta.get("command"), "kind": "citation of a separate rocprofv3 --pmc run (tools/gpu_pmc.sh), not measured by this run"}
+    if meta.get("sources_sha16") != sources_sha16():
+        src["note"] = "stale: kernels changed since that PMC run (current sources_sha16 %s); traffic withheld" % sources_sha16()
+        return None, src
+    return float(d["_step_hbm_bytes"]), src
+
+
+def device_times(step, steps, torch):
+    """Per-step device time (ms) of `steps` back-to-back steps: one HIP event before each step and one after the last, on
+    the stream the kernels are launched on.  Outside the timed region (the extra events would perturb it)."""
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    for i in range(steps):
+        evs[i].record()
+        step()
+    evs[steps].record()
+    torch.cuda.synchronize()
+    return [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+
+
+def spread(ms):
+    srt = sorted(ms)
+    return {"min": srt[0], "median": statistics.median(srt), "p90": srt[min(len(srt) - 1, int(0.9 * len(srt)))], "max": srt[-1],
+            "n": len(srt)}
 
 
 def main():
@@ -104,10 +146,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--algo", default="auto", choices=["auto", "direct", "table"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every rank generates a full 2^26 window; strong: ONE 2^26 window over the ranks "
+                         "(interleaved ownership parts, BASELINE config C5)")
+    ap.add_argument("--algo", default="auto", choices=["auto", "direct", "table", "fused"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--ramp-seconds", type=float, default=1.0, help="untimed back-to-back steps before the warmup (clock ramp)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for the barrier / max-over-ranks (nccl = RCCL; gloo only to rehearse N>1 "
                          "on a box with fewer GPUs than ranks, together with BHW_BENCH_SHARE_GPU=1)")
@@ -137,15 +183,32 @@ def main():
         else:
             dist.init_process_group(backend="gloo")
 
-    algo = {"auto": B.ALGO_AUTO, "direct": B.ALGO_DIRECT, "table": B.ALGO_TABLE}[args.algo]
+    algo = {"auto": B.ALGO_AUTO, "direct": B.ALGO_DIRECT, "table": B.ALGO_TABLE, "fused": B.ALGO_FUSED}[args.algo]
     params = bhw.make_params(WIN, PHI_WIDTH, DAT_WIDTH)          # model HLS + HLS combine + built-in a_k
-    n0, count = shard_for(rank)
-    out = torch.empty(count, dtype=torch.int32, device=dev)
-    ws_bytes = B.lib().bhw_workspace_bytes(ctypes.byref(params), n0, count, algo)
-    workspace = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    strong = args.scaling == "strong"
+    workspace = None
+    if strong:
+        # one window over the ranks: this rank's ownership part, written in place into a full-length buffer
+        out = torch.empty(COUNT, dtype=torch.int32, device=dev)
+        ws_bytes = B.lib().bhw_workspace_bytes(ctypes.byref(params), 0, COUNT, B.ALGO_TABLE)
+        workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        segments = B.part_segments(params, rank, world)
+        units_per_step = COUNT                                 # whole job: one window per step
+        my_units = sum(c for _, c in segments)
+        plan = "interleaved ownership part %d/%d (%d segments, %d coefficients)" % (rank, world, len(segments), my_units)
 
-    def step():
-        bhw.generate(params, n0, count, out=out, algo=algo, workspace=workspace if ws_bytes else None)
+        def step():
+            bhw.generate_part(params, rank, world, out, algo=algo, workspace=workspace)
+    else:
+        n0, count = shard_for(rank)
+        out = torch.empty(count, dtype=torch.int32, device=dev)
+        ws_bytes = B.lib().bhw_workspace_bytes(ctypes.byref(params), n0, count, algo)
+        workspace = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        units_per_step = world * count
+        my_units = count
+
+        def step():
+            bhw.generate(params, n0, count, out=out, algo=algo, workspace=workspace if ws_bytes else None)
 
     def barrier():
         if dist is not None:
@@ -161,7 +224,6 @@ def main():
     # device-side duration of the K timed steps on the launch stream (HIP events), for the roofline figure
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     state = {"n": 0}
-    table_algo = ws_bytes > 0
 
     def step_with_events():
         if state["n"] == 0:
@@ -171,10 +233,16 @@ def main():
         if state["n"] == args.steps:
             ev1.record()
 
-    # untimed: let the device clocks ramp (the first ~50 ms after idle run ~8 % slower), then the W warmup steps
+    # untimed: settle the lazy per-configuration work (table format verification) and let the device clocks ramp -- the first
+    # steps after idle run up to ~10 % slower, and a cold box needs about a second of load before the rate is flat
+    step()
+    torch.cuda.synchronize()
     t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < 0.1:
-        step()
+    ramp_steps = 0
+    while time.perf_counter() - t_ramp < args.ramp_seconds:
+        for _ in range(50):
+            step()
+        ramp_steps += 50
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
@@ -182,10 +250,15 @@ def main():
     dev_ms = ev0.elapsed_time(ev1) / args.steps
     dev_ms = allreduce_max(dev_ms)
 
+    # per-step device-time distribution over K more steps (outside the timed region)
+    step_ms = spread(device_times(step, args.steps, torch))
+
     # per-kernel split, outside the timed region: a few extra steps with the library's event recorded between
     # the table build and the combine pass (cross-check for the rocprofv3 kernel stats under profiles/)
+    plan_line = B.describe_plan(params, 0 if strong else n0, COUNT, algo) if not strong else None
     per_kernel = None
-    if table_algo:
+    if not strong and plan_line.startswith("table"):
+        names = plan_line.split(": ", 1)[1].split(" + ")
         reps = min(10, args.steps)
         evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(reps)]
         for trio in evs:
@@ -199,8 +272,8 @@ def main():
         torch.cuda.synchronize()
         build_us = sum(t[0].elapsed_time(t[1]) for t in evs) / reps * 1e3
         comb_us = sum(t[1].elapsed_time(t[2]) for t in evs) / reps * 1e3
-        per_kernel = {"k_table_build_shared": {"avg_us": build_us},
-                      "k_table_combine_tile": {"avg_us": comb_us, "dominant": True,
+        per_kernel = {names[0]: {"avg_us": build_us},
+                      names[1].split(" ")[0]: {"avg_us": comb_us, "dominant": True,
                                                "achieved_alone_GBps": BYTES_PER_COEFF * count / (comb_us * 1e-6) / 1e9},
                       "note": "event-to-event, includes the launch gap; rocprofv3 kernel stats under profiles/"}
 
@@ -211,37 +284,74 @@ def main():
     try:
         with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
             g = json.load(f)["entries"]["C3_bh7_26_32"]
-        parity = all(int(out[int(n)]) == v for n, v in g["sparse"].items())
         step_s = (1 << 23) // 1024
-        for sh, e in enumerate(g["shards"]):
-            seg = out[sh << 23:(sh + 1) << 23]
-            parity = parity and int(seg.sum(dtype=torch.int64)) == e["sum"]
-            parity = parity and seg[::step_s][:1024].cpu().tolist() == e["strided_1024"]
-        parity = bool(parity)
+        if strong and world > 1:
+            # this rank holds only its segments: every golden sample inside them must match
+            owned = torch.zeros(COUNT, dtype=torch.bool, device=dev)
+            for s0, c in segments:
+                owned[s0:s0 + c] = True
+            parity = True
+            for sh, e in enumerate(g["shards"]):
+                idx = (sh << 23) + step_s * torch.arange(1024, device=dev)
+                want = torch.tensor(e["strided_1024"], dtype=torch.int32, device=dev)
+                m = owned[idx]
+                parity = parity and bool((out[idx][m] == want[m]).all())
+            parity = bool(parity) and allreduce_max(0.0 if parity else 1.0) == 0.0
+        else:
+            parity = all(int(out[int(n)]) == v for n, v in g["sparse"].items())
+            for sh, e in enumerate(g["shards"]):
+                seg = out[sh << 23:(sh + 1) << 23]
+                parity = parity and int(seg.sum(dtype=torch.int64)) == e["sum"]
+                parity = parity and seg[::step_s][:1024].cpu().tolist() == e["strided_1024"]
+            parity = bool(parity)
     except FileNotFoundError:
         pass
 
-    total = world * args.steps * count
+    # the same step with the cpp model's cosines (cpp/cordic_sincos.cpp: the bit-model pinned by the reference's own compiled
+    # cordic(), tests/test_gpu_reference_pin.py) -- untimed extra leg, so the pinned model's rate is in the record too
+    cpp_leg = None
+    if not strong and rank == 0:
+        pc = bhw.make_params(WIN, PHI_WIDTH, DAT_WIDTH, model=B.MODEL_CPP)
+
+        def step_cpp():
+            bhw.generate(pc, n0, count, out=out, algo=algo, workspace=workspace if ws_bytes else None)
+        for _ in range(5):
+            step_cpp()
+        torch.cuda.synchronize()
+        ms = spread(device_times(step_cpp, min(args.steps, 50), torch))
+        cpp_leg = {"ms_per_step_median": ms["median"], "Gsamples_per_s": count / (ms["median"] * 1e-3) / 1e9,
+                   "plan": B.describe_plan(pc, n0, count, algo),
+                   "note": "same window, CORDIC bit-model of cpp/cordic_sincos.cpp (BHW_MODEL_CPP) in the HLS cosine-sum; device time"}
+        step()                                                  # leave the headline window in `out`
+
+    total = units_per_step * args.steps
     value = total / elapsed / 1e9
-    achieved = BYTES_PER_COEFF * count / (dev_ms * 1e-3) / 1e9
+    # roofline: algorithmic bytes of what THIS device wrote per step / its device time per step
+    achieved = BYTES_PER_COEFF * my_units / (dev_ms * 1e-3) / 1e9
+    traffic, traffic_source = pmc_traffic() if (not strong and args.algo in ("auto", "table")) else (None, {"file": None})
     rec = {
         "metric": "window Gsamples/s (BH-7, N=2^26, 32-bit) + fraction of HBM-write roofline",
         "value": value, "unit": "Gsamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[2]: Blackman-Harris 7-term, N=2^26 (64M), 32-bit output, model HLS CORDIC + HLS cosine-sum",
-                   "phi_width": PHI_WIDTH, "dat_width": DAT_WIDTH, "n_terms": 7, "coefficients_per_step_per_gpu": count,
-                   "strategy": args.algo, "sharding": "contiguous stream-index range per rank, no collective"},
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+        "vs_baseline": None, "dtype": "int64", "output_dtype": "int32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: Blackman-Harris 7-term, N=2^26 (64M), 32-bit output, model HLS CORDIC + HLS cosine-sum"
+                               + (" -- ONE window over the ranks (configs[4], C5)" if strong else ""),
+                   "phi_width": PHI_WIDTH, "dat_width": DAT_WIDTH, "n_terms": 7,
+                   "coefficients_per_step_per_gpu": my_units, "strategy": args.algo,
+                   "plan": plan if strong else plan_line,
+                   "sharding": ("interleaved ownership parts of one window, no collective" if strong else
+                                "contiguous stream-index range per rank (one full window each), no collective")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic() if args.algo in ("auto", "table") else None,
-                     "device_ms_per_step": dev_ms,
-                     "algorithmic_bytes": BYTES_PER_COEFF * count, "per_kernel": per_kernel,
-                     "note": "achieved = 4 B x 2^26 coefficients / device time of one step (both kernels of the step: table build + "
-                             "tile combine; HIP events on the launch stream); traffic = HBM bytes per step from PMC (profiles/), "
-                             "above the algorithmic bytes because the strategy round-trips the first-quadrant (c,s) table (32 MiB in the "
-                             "residual format, read ~7x by the six harmonics)"},
+                     "traffic": traffic, "traffic_source": traffic_source,
+                     "device_ms_per_step": dev_ms, "device_ms_per_step_spread": step_ms,
+                     "algorithmic_bytes": BYTES_PER_COEFF * my_units, "per_kernel": per_kernel,
+                     "note": "achieved = 4 B x coefficients this device writes per step / device time of one step (every kernel of the "
+                             "step; HIP events on the launch stream around the K timed steps); spread = per-step event times of K "
+                             "further steps; dtype = widest arithmetic type on the path (64-bit CORDIC state), output int32"},
+        "ramp": {"seconds": args.ramp_seconds, "steps": ramp_steps},
         "parity_spot_check": parity,
+        "cpp_model": cpp_leg,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         rec["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.cpu_threads)

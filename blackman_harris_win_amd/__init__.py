@@ -14,17 +14,20 @@ The surface mirrors the reference's operator:
   * ``cordic(theta0, count, ...)``  <->  cordic() (cpp/cordic_sincos.cpp:10, hls/cordic/cordic.cpp:45).
 """
 from .binding import (  # noqa: F401
-    ALGO_AUTO, ALGO_DIRECT, ALGO_TABLE,
+    ALGO_AUTO, ALGO_DIRECT, ALGO_FUSED, ALGO_TABLE,
     TABLE_BEST, TABLE_DELTA16, TABLE_PLAIN, TABLE_RESIDUAL,
     COMBINE_HLS, COMBINE_VHDL,
     MODEL_CPP, MODEL_DDS48, MODEL_HLS, MODEL_SCALED, MODEL_VHDL,
     SIN_CORDIC, SIN_TAYLOR, SIN_TAYLOR_ALL,
     WIN_BH3, WIN_BH4, WIN_BH5, WIN_BH7, WIN_HAMMING, WIN_HANN,
-    BhwAtan2Params, BhwError, BhwParams, coeffs_from_float, constant_tables, lib, lib_path, make_params,
+    BhwAtan2Params, BhwError, BhwParams, coeffs_from_float, constant_tables, lib, lib_path, make_params, part_segments,
 )
-from .selector import WinSelector, apply, atan2, cordic, generate, generate_batched, prepare, shard_range, win_function  # noqa: F401
+from .selector import (  # noqa: F401
+    WinSelector, apply, atan2, cordic, generate, generate_batched, generate_part, prepare, shard_range, win_function,
+)
 
 __all__ = [
-    "WinSelector", "win_function", "cordic", "atan2", "generate", "generate_batched", "apply", "prepare", "shard_range",
+    "WinSelector", "win_function", "cordic", "atan2", "generate", "generate_batched", "generate_part", "part_segments", "apply",
+    "prepare", "shard_range",
     "make_params", "coeffs_from_float", "constant_tables", "BhwParams", "BhwError", "lib", "lib_path",
 ]

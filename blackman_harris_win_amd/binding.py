@@ -8,7 +8,7 @@ MODEL_HLS, MODEL_CPP, MODEL_VHDL, MODEL_DDS48, MODEL_SCALED = 0, 1, 2, 3, 4
 COMBINE_HLS, COMBINE_VHDL = 0, 1
 SIN_CORDIC, SIN_TAYLOR, SIN_TAYLOR_ALL = 0, 1, 2
 WIN_HAMMING, WIN_HANN, WIN_BH3, WIN_BH4, WIN_BH5, WIN_BH7 = 1, 2, 3, 4, 5, 7
-ALGO_AUTO, ALGO_DIRECT, ALGO_TABLE = 0, 1, 2
+ALGO_AUTO, ALGO_DIRECT, ALGO_TABLE, ALGO_FUSED = 0, 1, 2, 3
 TABLE_BEST, TABLE_PLAIN, TABLE_DELTA16, TABLE_RESIDUAL = 0, 1, 2, 3
 ABI_VERSION = 2
 
@@ -18,7 +18,7 @@ ABI_SYMBOLS = (
     "bhw_coeffs_from_float", "bhw_constant_tables", "bhw_generate_device", "bhw_generate_device_ex",
     "bhw_workspace_bytes", "bhw_generate_batched_device", "bhw_sincos_device", "bhw_generate_to_host",
     "bhw_sincos_to_host", "bhw_release_device", "bhw_apply_device", "bhw_atan2_device", "bhw_atan2_to_host",
-    "bhw_prepare_device",
+    "bhw_prepare_device", "bhw_part_segments", "bhw_generate_part_device", "bhw_describe_plan",
 )
 
 
@@ -43,6 +43,10 @@ class BhwAtan2Params(ctypes.Structure):
     """struct bhw_atan2_params of include/bhw.h (generics of entity cordic_atan2, src/cordic_atan2.vhd:64-69)."""
     _fields_ = [("struct_size", ctypes.c_uint32), ("precision", ctypes.c_uint32),
                 ("input_width", ctypes.c_uint32), ("angle_width", ctypes.c_uint32)]
+
+
+class BhwSegment(ctypes.Structure):
+    _fields_ = [("n0", ctypes.c_uint64), ("count", ctypes.c_uint64)]
 
 
 class BhwExec(ctypes.Structure):
@@ -96,6 +100,9 @@ def lib():
     L.bhw_sincos_to_host.argtypes = [P, ci, u64, u64, i32p, i32p]
     L.bhw_release_device.argtypes = [ci]
     L.bhw_prepare_device.argtypes = [P, ci, vp]
+    L.bhw_describe_plan.argtypes = [P, u64, u64, ctypes.POINTER(BhwExec), ctypes.c_char_p, u64]
+    L.bhw_part_segments.argtypes = [P, u32, u32, ctypes.POINTER(BhwSegment), u32, ctypes.POINTER(u32)]
+    L.bhw_generate_part_device.argtypes = [P, ci, vp, u32, u32, i32p, ctypes.POINTER(BhwExec)]
     L.bhw_apply_device.argtypes = [P, ci, vp, u64, u64, i32p, i32p, u32]
     PA = ctypes.POINTER(BhwAtan2Params)
     L.bhw_atan2_device.argtypes = [PA, ci, vp, u64, i32p, i32p, i32p]
@@ -110,6 +117,25 @@ def lib():
 def check(rc):
     if rc != 0:
         raise BhwError(rc, lib().bhw_last_error().decode(errors="replace"))
+
+
+def describe_plan(params, n0, count, algo=ALGO_AUTO, table_format=TABLE_BEST):
+    """One line: strategy, table format and kernel names a call would launch now (bhw_describe_plan)."""
+    ex = BhwExec()
+    ex.struct_size = ctypes.sizeof(BhwExec)
+    ex.algo = algo
+    ex.table_format = table_format
+    buf = ctypes.create_string_buffer(256)
+    check(lib().bhw_describe_plan(ctypes.byref(params), int(n0), int(count), ctypes.byref(ex), buf, 256))
+    return buf.value.decode()
+
+
+def part_segments(params, part, n_parts):
+    """[(n0, count), ...]: the coefficients interleaved-ownership part `part` of `n_parts` owns (bhw_part_segments).  Host arithmetic."""
+    n = ctypes.c_uint32()
+    segs = (BhwSegment * 256)()
+    check(lib().bhw_part_segments(ctypes.byref(params), part, n_parts, segs, 256, ctypes.byref(n)))
+    return [(int(segs[i].n0), int(segs[i].count)) for i in range(n.value)]
 
 
 def coeffs_from_float(win_type, dat_width, a=None):

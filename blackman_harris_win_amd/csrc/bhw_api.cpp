@@ -311,11 +311,28 @@ bool device_ok(int device)
 
 uint64_t table_entries(const BhwCordicCfg &c) { return 1ull << (c.phi_width - 2 - c.z_shr); }
 
-// AUTO: build the shared table when it replaces clearly more CORDIC chains than it costs.
-uint32_t pick_algo(const bhw_params *p, const BhwCordicCfg &c, uint64_t count, uint32_t requested)
+bool has_whole_period(const bhw_params *p, uint64_t n0, uint64_t count)
+{
+    const uint64_t N = 1ull << p->phi_width;
+    return count >= (N - n0 % N) % N + N;
+}
+
+// Whole periods up to this length go through the fused kernel under AUTO: one launch of 9/8 chains per coefficient beats two
+// dependent launches around a table of 1/4 chain per coefficient while the call is launch- and latency-bound
+// (measured: profiles/r02_small_windows.json).
+#ifndef BHW_FUSED_MAX_PW
+#define BHW_FUSED_MAX_PW 20
+#endif
+
+// AUTO: the fused kernel for short whole periods; else build the shared table when it replaces clearly more CORDIC chains
+// than it costs; else one chain per harmonic per coefficient.
+uint32_t pick_algo(const bhw_params *p, const BhwCordicCfg &c, uint64_t n0, uint64_t count, uint32_t requested)
 {
     if (p->sin_type != BHW_SIN_CORDIC) return BHW_ALGO_DIRECT;
+    const bool fused_ok = bhwk_fold_direct_applicable(c) && has_whole_period(p, n0, count);
+    if (requested == BHW_ALGO_FUSED) return fused_ok ? BHW_ALGO_FUSED : BHW_ALGO_TABLE;
     if (requested == BHW_ALGO_DIRECT || requested == BHW_ALGO_TABLE) return requested;
+    if (fused_ok && p->phi_width <= BHW_FUSED_MAX_PW) return BHW_ALGO_FUSED;
     const uint64_t chains_direct = count * (p->n_terms - 1);
     return chains_direct >= 2 * table_entries(c) ? BHW_ALGO_TABLE : BHW_ALGO_DIRECT;
 }
@@ -453,10 +470,25 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
     }
     BhwCordicCfg c;
     resolve_cordic(p, c);
-    const uint32_t algo = pick_algo(p, c, count, ex ? ex->algo : BHW_ALGO_AUTO);
+    const uint32_t algo = pick_algo(p, c, n0, count, ex ? ex->algo : BHW_ALGO_AUTO);
     if (algo == BHW_ALGO_DIRECT) {
         int e = bhwk_direct(l, c, w, n0, count, d_out);
         return e ? fail_hip(e, "direct launch") : BHW_OK;
+    }
+    if (algo == BHW_ALGO_FUSED) {
+        // head | whole periods | tail: each whole period is one launch of the fused kernel over the full ring, the ragged
+        // ends take the direct kernel; nothing is allocated and no table exists
+        const uint64_t NF = 1ull << p->phi_width;
+        const BhwFoldRun ring{0u, 1u << (p->phi_width - 3)};
+        auto ragged = [&](uint64_t off, uint64_t len) -> int {
+            if (apply_x) w.apply_x = apply_x + off;
+            return bhwk_direct(l, c, w, n0 + off, len, d_out + off);
+        };
+        auto period = [&](uint64_t off) -> int {
+            if (apply_x) w.apply_x = apply_x + off;
+            return bhwk_fold_direct(l, c, w, &ring, 1, d_out + off);
+        };
+        return run_split(l, n0, count, NF, apply_x != nullptr, d_out, ragged, period);
     }
     const uint64_t need = table_entries(c) * 8ull;
     void *ws = nullptr;
@@ -599,12 +631,58 @@ int bhw_apply_device(const bhw_params *p, int device, void *hip_stream, uint64_t
 
 uint64_t bhw_workspace_bytes(const bhw_params *p, uint64_t n0, uint64_t count, uint32_t algo)
 {
-    (void)n0;
     if (validate(p)) return 0;
     if (p->sin_type != BHW_SIN_CORDIC) return 0;
     BhwCordicCfg c;
     resolve_cordic(p, c);
-    return pick_algo(p, c, count, algo) == BHW_ALGO_TABLE ? table_entries(c) * 8ull : 0;
+    return pick_algo(p, c, n0, count, algo) == BHW_ALGO_TABLE ? table_entries(c) * 8ull : 0;
+}
+
+int bhw_describe_plan(const bhw_params *p, uint64_t n0, uint64_t count, const bhw_exec *ex, char *buf, uint64_t len)
+{
+    int rc = validate(p);
+    if (rc) return rc;
+    rc = check_exec(ex);
+    if (rc) return rc;
+    if (!buf || !len) return fail(BHW_ERR_BADARG, "buf is NULL or empty");
+    const bool period = has_whole_period(p, n0, count);
+    if (p->sin_type != BHW_SIN_CORDIC) {
+        snprintf(buf, len, "taylor: %s", period && p->phi_width >= 5 ? "k_taylor_window_fold (+ k_taylor_window on ragged ends)" : "k_taylor_window");
+        return BHW_OK;
+    }
+    BhwCordicCfg c;
+    resolve_cordic(p, c);
+    BhwWinCfg w;
+    resolve_window(p, w);
+    const uint32_t algo = pick_algo(p, c, n0, count, ex ? ex->algo : BHW_ALGO_AUTO);
+    if (algo == BHW_ALGO_DIRECT) {
+        snprintf(buf, len, "direct: %s", (c.dat_width + c.out_shr <= 34 && c.n_iter >= 7) ? "k_direct_fast" : "k_direct");
+        return BHW_OK;
+    }
+    if (algo == BHW_ALGO_FUSED) {
+        snprintf(buf, len, "fused: k_fold_direct<%u,%d> (+ k_direct_fast on ragged ends)", p->n_terms,
+                 (w.combine != BHW_COMBINE_HLS) ? 2 : (c.ones_neg ? 1 : 0));
+        return BHW_OK;
+    }
+    const bool tiled = period && bhwk_tile_applicable(c, w);
+    c.tab_split = (tiled && c.z_shr == 0) ? 1u : 0u;
+    uint32_t cand[3];
+    const int n_cand = table_format_candidates(c, tiled, exec_table_format(ex), cand);
+    const char *state = "";
+    c.tab_dlog = 0;
+    for (int i = 0; i < n_cand; ++i) {
+        const int v = cand[i] ? fmt_verdict(p, cand[i]) : (int)kFmtOk;
+        if (v == kFmtBad) continue;
+        c.tab_dlog = cand[i];
+        if (v == kFmtUnknown) state = ", unverified";
+        break;
+    }
+    char build[64], combine[64];
+    bhwk_describe_table(c, w, tiled, build, combine, sizeof build);
+    const char *fmt = c.tab_dlog == 0 ? "plain" : c.tab_dlog == 6 ? "delta16" : "residual";
+    snprintf(buf, len, "table[%s%s]: %s + %s%s", fmt, state, build, period ? combine : "k_table_combine",
+             period && count != (1ull << p->phi_width) ? " (+ k_table_combine / k_replicate on the rest)" : "");
+    return BHW_OK;
 }
 
 int bhw_generate_batched_device(const bhw_params *p, int device, void *hip_stream, uint32_t frames, int32_t *d_out)
@@ -838,6 +916,119 @@ int bhw_atan2_to_host(const bhw_atan2_params *p, int device, uint64_t count, con
     }
     (void)hipFree(d);
     return rc;
+}
+
+// ---- interleaved ownership parts (include/bhw.h) ------------------------------------------------------------------------
+namespace {
+int part_checks(const bhw_params *p, uint32_t part, uint32_t n_parts)
+{
+    int rc = validate(p);
+    if (rc) return rc;
+    if (p->sin_type != BHW_SIN_CORDIC) return fail(BHW_ERR_UNSUPPORTED, "interleaved parts exist for the CORDIC source only");
+    if (n_parts < 1 || n_parts > 64 || part >= n_parts) return fail(BHW_ERR_BADARG, "part %u of %u (1..64 parts)", part, n_parts);
+    if (p->phi_width < 9) return fail(BHW_ERR_UNSUPPORTED, "interleaved parts need phi_width >= 9 (a ring of 64 lanes)");
+    return BHW_OK;
+}
+} // namespace
+
+int bhw_part_segments(const bhw_params *p, uint32_t part, uint32_t n_parts, bhw_segment *segs, uint32_t capacity, uint32_t *n_segs)
+{
+    int rc = part_checks(p, part, n_parts);
+    if (rc) return rc;
+    if (!n_segs) return fail(BHW_ERR_BADARG, "n_segs is NULL");
+    BhwCordicCfg c;
+    resolve_cordic(p, c);
+    BhwWinCfg w;
+    resolve_window(p, w);
+    BhwFoldRun runs[32];
+    uint32_t t0, tc;
+    const int n_runs = bhwk_part_runs(c, w, part, n_parts, runs, &t0, &tc);
+    std::vector<bhw_segment> all;
+    const uint64_t H = 1ull << (p->phi_width - 3);
+    for (int i = 0; i < n_runs; ++i)
+        for (uint64_t img = 0; img < 8; ++img)
+            all.push_back(bhw_segment{runs[i].r0 + img * H, (uint64_t)(runs[i].r_end - runs[i].r0)});
+    // sorted, touching or overlapping segments merged
+    for (size_t i = 1; i < all.size(); ++i)
+        for (size_t j = i; j > 0 && all[j - 1].n0 > all[j].n0; --j) std::swap(all[j - 1], all[j]);
+    std::vector<bhw_segment> merged;
+    for (const bhw_segment &sg : all) {
+        if (!merged.empty() && sg.n0 <= merged.back().n0 + merged.back().count) {
+            const uint64_t end = sg.n0 + sg.count;
+            if (end > merged.back().n0 + merged.back().count) merged.back().count = end - merged.back().n0;
+        } else merged.push_back(sg);
+    }
+    *n_segs = (uint32_t)merged.size();
+    if (segs) {
+        if (capacity < merged.size()) return fail(BHW_ERR_BADARG, "capacity %u < %zu segments", capacity, merged.size());
+        for (size_t i = 0; i < merged.size(); ++i) segs[i] = merged[i];
+    }
+    return BHW_OK;
+}
+
+int bhw_generate_part_device(const bhw_params *p, int device, void *hip_stream, uint32_t part, uint32_t n_parts,
+                             int32_t *d_window, const bhw_exec *ex)
+{
+    int rc = part_checks(p, part, n_parts);
+    if (rc) return rc;
+    if (!d_window) return fail(BHW_ERR_BADARG, "d_window is NULL");
+    rc = check_exec(ex);
+    if (rc) return rc;
+    if (!device_ok(device)) return fail(BHW_ERR_HIP, "no usable HIP device %d (this library has no CPU path)", device);
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
+    BhwLaunch l{device, hip_stream};
+    BhwCordicCfg c;
+    resolve_cordic(p, c);
+    BhwWinCfg w;
+    resolve_window(p, w);
+    BhwFoldRun runs[32];
+    uint32_t tile0 = 0, tile_count = 0;
+    const int n_runs = bhwk_part_runs(c, w, part, n_parts, runs, &tile0, &tile_count);
+    if (n_runs == 0) return BHW_OK;
+    uint64_t lanes = 0;
+    for (int i = 0; i < n_runs; ++i) lanes += runs[i].r_end - runs[i].r0;
+    // Strategy.  Fused: chains = lanes x (chains per lane), no table.  Table: the full first-quadrant table (it does not
+    // shrink with the part) + this part's tiles.  The fused kernel wins once the part is small enough.
+    static const int kChains[8] = {0, 0, 2, 3, 5, 6, 0, 9};
+    const uint64_t chains_fused = lanes * (uint64_t)kChains[p->n_terms];
+    const uint32_t req = ex ? ex->algo : (uint32_t)BHW_ALGO_AUTO;
+    const bool fused_ok = bhwk_fold_direct_applicable(c);
+    const bool table_ok = tile_count != 0;                     // tile-aligned ownership: the tile kernel can produce exactly this part
+    bool fused;
+    if (req == BHW_ALGO_FUSED) fused = fused_ok;
+    else if (req == BHW_ALGO_TABLE) fused = !table_ok;
+    else fused = fused_ok && (!table_ok || chains_fused <= table_entries(c));
+    if (fused) {
+        if (!fused_ok) return fail(BHW_ERR_UNSUPPORTED, "no kernel produces this part (CORDIC state beyond 34 bits and no tile plan)");
+        const int e = bhwk_fold_direct(l, c, w, runs, (uint32_t)n_runs, d_window);
+        return e ? fail_hip(e, "fused part launch") : BHW_OK;
+    }
+    if (!table_ok) return fail(BHW_ERR_UNSUPPORTED, "the table strategy produces whole tiles only and this window has no tile plan");
+    const uint64_t need = table_entries(c) * 8ull;
+    void *ws = nullptr;
+    std::shared_ptr<Slot> slot;
+    std::unique_lock<std::mutex> slot_lock;
+    if (ex && ex->workspace) {
+        if (ex->workspace_bytes < need)
+            return fail(BHW_ERR_WORKSPACE, "workspace %llu < %llu bytes", (unsigned long long)ex->workspace_bytes, (unsigned long long)need);
+        ws = ex->workspace;
+    } else {
+        slot = slot_of(device, hip_stream);
+        slot_lock = std::unique_lock<std::mutex>(slot->mu);
+        rc = ensure_slot_bytes(*slot, hip_stream, need);
+        if (rc) return rc;
+        ws = slot->buf;
+    }
+    c.tab_split = c.z_shr == 0 ? 1u : 0u;
+    rc = build_table(p, l, c, true, exec_table_format(ex), ws);
+    if (rc) return rc;
+    if (ex && ex->event_after_build) {
+        hipError_t he = hipEventRecord((hipEvent_t)ex->event_after_build, (hipStream_t)hip_stream);
+        if (he != hipSuccess) return fail_hip(he, "hipEventRecord(event_after_build)");
+    }
+    const int e = bhwk_table_combine_tile_range(l, c, w, (const int32_t *)ws, d_window, tile0, tile_count);
+    return e ? fail_hip(e, "tile part launch") : BHW_OK;
 }
 
 int bhw_release_device(int device)

@@ -1,5 +1,6 @@
 // bhw_internal.h -- structures shared by the host-side ABI (bhw_api.cpp) and the HIP kernels.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 #include "../../include/bhw.h"
 
@@ -86,6 +87,18 @@ int bhwk_table_combine_fold(const BhwLaunch &l, const BhwCordicCfg &c, const Bhw
 // whole period, 15-block super-tiles over the residue-split table (z_shr == 0 only)
 int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out);
 bool bhwk_tile_applicable(const BhwCordicCfg &c, const BhwWinCfg &w);
+void bhwk_describe_table(const BhwCordicCfg &c, const BhwWinCfg &w, bool tiled, char *build, char *combine, size_t len);
+// tiles [tile0, tile0 + tile_count) of the tile plan only (tile_count 0: the whole ring)
+int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out,
+                                  uint32_t tile0, uint32_t tile_count);
+// Fused fold kernel (no table): for every ring lane r of the runs, the eight coefficients r + h*N/8 + j*N/4 into the
+// full-window buffer d_out.  At most 32 runs.
+struct BhwFoldRun { uint32_t r0, r_end; };
+bool bhwk_fold_direct_applicable(const BhwCordicCfg &c);
+int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const BhwFoldRun *runs, uint32_t n_runs, int32_t *d_out);
+// ring lanes of interleaved-ownership part `part` of `n_parts` as runs (returns the count, <= 32); tile0 / tile_count: the same
+// part as a range of the tile plan's tiles when the tile kernel applies (tile_count 0 otherwise)
+int bhwk_part_runs(const BhwCordicCfg &c, const BhwWinCfg &w, uint32_t part, uint32_t n_parts, BhwFoldRun *runs, uint32_t *tile0, uint32_t *tile_count);
 int bhwk_taylor_window(const BhwLaunch &l, const BhwTaylorCfg &t, const BhwWinCfg &w,
                        uint64_t n0, uint64_t count, int32_t *d_out);
 // one whole period [0, 2^PW) with the quadrant fold (PW >= 5)

@@ -7,6 +7,8 @@
 //
 // Integer semantics follow SURVEY App. A; reference lines are cited at each step.
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
 #include <type_traits>
 #include "bhw_internal.h"
 
@@ -617,7 +619,8 @@ constexpr int kTileLanes = BHW_TILE_LANES;     // tile width in lanes; the tile'
 
 struct BhwTilePlan {
     uint32_t offs[16];   // (i3*inv3 + i5*inv5) mod ring, index i3 + 3*i5; padded by repeating the last run
-    uint32_t n_tiles;
+    uint32_t n_tiles;    // tiles that cover the ring once
+    uint32_t tile0;      // first tile of this launch (interleaved ownership parts launch a sub-range of the tiles)
 };
 
 __device__ __forceinline__ int32_t wrap32(int32_t v, uint32_t bits)
@@ -797,7 +800,7 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
     uint32_t rr[NR];
 #pragma unroll
     for (int b = 0; b < NR; ++b) {
-        const uint32_t start = (blockIdx.x * kLanes + tp.offs[part * NR + b]) & hmask;   // scalar; offs padded with copies of the last run
+        const uint32_t start = ((blockIdx.x + tp.tile0) * kLanes + tp.offs[part * NR + b]) & hmask;   // scalar; offs padded with copies of the last run
         rr[b] = (start + (lane_in_part + kLanes - (start & 63u)) % kLanes) & hmask;
     }
     acc_t acc[NR][2][4];
@@ -876,6 +879,154 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
                         (int32_t)(((int64_t)xv[h][j] * (int64_t)final_value(b, h, j)) >> win.apply_shift);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused fold kernel: whole-period work in ONE launch, no table.
+//
+// Lane r of the ring [0, N/8) owns the eight coefficients n = r + h*N/8 + j*N/4 (the quadrant + half-period fold of the tile
+// kernel) and runs the first-quadrant CORDIC chains they need itself: two per odd harmonic (entries K*r and K*r + E/2), one
+// per even harmonic -- 9 chains for 8 coefficients of a 7-term window instead of 48 in the direct kernel.  The 64 lanes of a
+// wave are consecutive r, so for every chain their leaves are equally spaced in angle and share a rotation prefix exactly as
+// the 64-leaf groups of k_table_build_shared do: phase 1 runs the (waves x chains) shared prefixes, one lane each, and parks
+// them in LDS; phase 2 is one lane per r.  Rotation count is a run-time bound on the unrolled steps (scalar guards), so one
+// instance serves every width.
+//
+// Used for (a) short whole windows (2^9 .. ~2^20 coefficients), where the table strategy is two dependent launches around a
+// table round trip, and (b) interleaved ownership parts of a long window (bhw_generate_part_device): a device that owns 1/G of
+// the ring needs 9/8G chains per coefficient of the whole window, below the table's 1/4 once G >= 5.
+// The lanes of a launch are a list of runs of consecutive r (one run for a whole window; the 15 sibling runs of the tile plan,
+// split where they wrap, for an ownership part).
+// ---------------------------------------------------------------------------------------
+constexpr int kFoldRunsMax = 32;
+constexpr int kFoldBlock = 256;
+
+struct BhwFoldPlan {
+    uint32_t lut[32];                        // rescaled ROM as 32-bit words (quarter circle <= 2^32)
+    int64_t  x0;
+    uint32_t n_iter, z_shr, z_shl, out_shr;
+    uint32_t n_runs, pad;
+    uint32_t r0[kFoldRunsMax];               // first ring index of each run
+    uint32_t r_end[kFoldRunsMax];            // one past its last
+    uint32_t wg_first[kFoldRunsMax + 1];     // first workgroup of each run; [n_runs] = grid size
+};
+
+__host__ __device__ constexpr int fold_chains(int n_terms)      // first-quadrant chains per ring lane
+{
+    return n_terms == 2 ? 2 : n_terms == 3 ? 3 : n_terms == 4 ? 5 : n_terms == 5 ? 6 : 9;
+}
+
+// Remaining rotations of one chain from rotation k0 on: fully unrolled (immediate shifts, ROM words as scalar kernel
+// arguments), k0 and n_iter wave-uniform, so every guard is a scalar compare-and-branch.
+__device__ __forceinline__ void chain_from(int64_t &x, int64_t &y, int32_t &z, int k0, int n_iter, const BhwFoldPlan &plan)
+{
+#pragma unroll
+    for (int k = 1; k < 32; ++k)
+        if (k >= k0 && k < n_iter) rot_step(x, y, z, k, plan.lut[k]);
+}
+
+template <int NTERMS, int MODE>
+__global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwCordicCfg cfg, BhwWinCfg win, BhwFoldPlan plan, int32_t *__restrict__ out)
+{
+    using acc_t = typename std::conditional<MODE == 2, Sum32, int32_t>::type;
+    constexpr int NCH = fold_chains(NTERMS);
+    constexpr int kWavesMax = kFoldBlock / 64;
+    __shared__ int64_t gx[kWavesMax * NCH], gy[kWavesMax * NCH];
+    __shared__ uint32_t gdz[kWavesMax * NCH];
+    __shared__ int32_t gk[kWavesMax * NCH];
+
+    const uint32_t lq = cfg.phi_width - 2;
+    const uint32_t E = 1u << lq, emask = E - 1u, H = E >> 1;
+    const uint32_t W = cfg.dat_width;
+    const int n_iter = (int)plan.n_iter;
+    uint32_t run = 0;                                                     // scalar search: at most kFoldRunsMax runs
+    while (run + 1u < plan.n_runs && blockIdx.x >= plan.wg_first[run + 1u]) ++run;
+    const uint32_t wg_r0 = plan.r0[run] + (blockIdx.x - plan.wg_first[run]) * blockDim.x;
+    const uint32_t r_end = plan.r_end[run];
+    const uint32_t n_waves = blockDim.x >> 6;
+
+    // ---- phase 1: shared rotation prefix of every (wave, chain) ----
+    // chain slot c -> harmonic K and half-period image: (1,0) (1,1) (2) (3,0) (3,1) (4) (5,0) (5,1) (6)
+    if (threadIdx.x < n_waves * NCH) {
+        const uint32_t wv = threadIdx.x / NCH, c = threadIdx.x % NCH;
+        const uint32_t K = 2u * (c / 3u) + 1u + (c % 3u == 2u ? 1u : 0u);
+        const uint32_t hodd = (c % 3u == 1u) ? 1u : 0u;
+        const uint32_t rf = wg_r0 + (wv << 6);
+        const uint32_t t0 = (K * rf + hodd * H) & emask;
+        const uint32_t tl = t0 + 63u * K;                                 // last leaf, if the 64 leaves do not wrap past E
+        const uint32_t z0f = (t0 >> plan.z_shr) << plan.z_shl;
+        bool live = tl <= emask;                                          // wrapped groups are not contiguous in angle: no sharing
+        const uint32_t span = live ? ((tl >> plan.z_shr) << plan.z_shl) - z0f : 0u;
+        int64_t x = plan.x0, y = plan.x0;                                 // after rotation 0 (z0 >= 0 always adds)
+        int32_t zf = (int32_t)(z0f - plan.lut[0]);
+        int k = 1;
+        constexpr int kmax = kPrefixMax < 32 ? kPrefixMax : 32;
+#pragma unroll
+        for (int kk = 1; kk < kmax; ++kk) {
+            if (live && kk < n_iter) {
+                const int32_t zl = (int32_t)((uint32_t)zf + span);
+                if ((zf < 0) != (zl < 0)) {
+                    live = false;                                         // the group splits at rotation kk
+                } else {
+                    rot_step(x, y, zf, kk, plan.lut[kk]);
+                    k = kk + 1;
+                }
+            }
+        }
+        gx[threadIdx.x] = x;
+        gy[threadIdx.x] = y;
+        gdz[threadIdx.x] = (uint32_t)zf - z0f;                            // z_k(leaf) = z0(leaf) + this, for every leaf of the group
+        gk[threadIdx.x] = k;
+    }
+    __syncthreads();
+
+    // ---- phase 2: one lane per r ----
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t r = wg_r0 + threadIdx.x;
+    acc_t acc[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (MODE == 2) acc[h][j] = Sum32{win.aa[0] >> 2, win.aa[0] & 3};
+            else acc[h][j] = win.aa[0];
+        }
+    auto chain = [&](const uint32_t slot, const uint32_t K, const uint32_t hodd) -> int2 {
+        const uint32_t i = wave * NCH + slot;                             // scalar: the parked state is read as a broadcast
+        int64_t x = gx[i], y = gy[i];
+        const int k0 = __builtin_amdgcn_readfirstlane(gk[i]);
+        const uint32_t t = (K * r + hodd * H) & emask;
+        int32_t z = (int32_t)(((t >> plan.z_shr) << plan.z_shl) + gdz[i]);
+        chain_from(x, y, z, k0, n_iter, plan);
+        return make_int2((int32_t)(x >> plan.out_shr), (int32_t)(y >> plan.out_shr));
+    };
+#define BHW_FD_HARMONIC(K)                                                                           \
+    if constexpr (NTERMS > K) {                                                                      \
+        constexpr uint32_t slot = ((K - 1) / 2) * 3 + ((K & 1) ? 0 : 2);                             \
+        int32_t sv[4];                                                                               \
+        const int2 cs0 = chain(slot, K, 0u);                                                         \
+        tile_harmonic<K, MODE>(cfg, win.aa[K], W, cs0, ((uint32_t)K * r) >> lq, sv);                 \
+        tile_accumulate<K, 0>(sv, acc[0]);                                                           \
+        if constexpr ((K & 1) != 0) {                                                                \
+            const int2 cs1 = chain(slot + 1u, K, 1u);                                                \
+            tile_harmonic<K, MODE>(cfg, win.aa[K], W, cs1, ((uint32_t)K * (r + H)) >> lq, sv);       \
+            tile_accumulate<K, 0>(sv, acc[1]);                                                       \
+        } else {                                                                                     \
+            tile_accumulate<K, K / 2>(sv, acc[1]);                                                   \
+        }                                                                                            \
+    }
+    BHW_FD_HARMONIC(1) BHW_FD_HARMONIC(2) BHW_FD_HARMONIC(3) BHW_FD_HARMONIC(4) BHW_FD_HARMONIC(5) BHW_FD_HARMONIC(6)
+#undef BHW_FD_HARMONIC
+    if (r >= r_end) return;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int32_t v;
+            if constexpr (MODE == 2) v = w32_final<BHW_COMBINE_VHDL>(acc[h][j], W, NTERMS);
+            else v = (int32_t)((uint32_t)acc[h][j] << (32u - W)) >> (32u - W);         // (win_t)(...) wrap to W bits
+            emit(win, out, (uint64_t)(r + (uint32_t)h * H) + (uint64_t)j * E, v);
+        }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1431,15 +1582,13 @@ bool bhwk_tile_applicable(const BhwCordicCfg &c, const BhwWinCfg &w)
     return c.phi_width >= BHW_TILE_MIN_PW && c.phi_width <= 30;
 }
 
-int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out)
+// The tile plan of a configuration: run offsets on the ring [0, N/8), lanes per run and tile, tiles that cover the ring.
+static void make_tile_plan(const BhwCordicCfg &c, const BhwWinCfg &w, BhwTilePlan &tp, int &nb, uint32_t &lanes)
 {
-    BHW_SET_DEVICE(l);
-    hipStream_t st = (hipStream_t)l.stream;
     const uint32_t lq = c.phi_width - 2, E = 1u << (lq - 1);   // the lane ring is [0, N/8): each lane owns r and r + N/8
     const uint32_t inv3 = inv_mod_pow2(3, lq - 1), inv5 = inv_mod_pow2(5, lq - 1);
     const int nb3 = (c.z_shr == 0 && w.n_terms > 3) ? 3 : 1, nb5 = (c.z_shr == 0 && w.n_terms > 5) ? 5 : 1;
-    const int nb = nb3 * nb5;
-    BhwTilePlan tp;
+    nb = nb3 * nb5;
     uint32_t sorted[15];
     for (int i5 = 0; i5 < nb5; ++i5)
         for (int i3 = 0; i3 < nb3; ++i3) {
@@ -1459,10 +1608,26 @@ int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const Bhw
         const uint64_t nxt = (i + 1 < nb) ? sorted[i + 1] : (uint64_t)sorted[0] + E;
         if (nxt - sorted[i] > maxgap) maxgap = nxt - sorted[i];
     }
-    const uint32_t lanes = (nb >= 15) ? (uint32_t)kTileLanes : (uint32_t)kTileThreads;
+    lanes = (nb >= 15) ? (uint32_t)kTileLanes : (uint32_t)kTileThreads;
     tp.n_tiles = (uint32_t)((maxgap + lanes - 1) / lanes);
+    tp.tile0 = 0;
+}
+
+// Tiles [tile0, tile0 + tile_count) of the plan (tile_count 0: all of them).
+int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out,
+                                  uint32_t tile0, uint32_t tile_count)
+{
+    BHW_SET_DEVICE(l);
+    hipStream_t st = (hipStream_t)l.stream;
+    BhwTilePlan tp;
+    int nb;
+    uint32_t lanes;
+    make_tile_plan(c, w, tp, nb, lanes);
+    if (tile_count == 0) { tile0 = 0; tile_count = tp.n_tiles; }
+    if (tile0 + tile_count > tp.n_tiles) return (int)hipErrorInvalidValue;
+    tp.tile0 = tile0;
     const int mode = (w.combine != BHW_COMBINE_HLS) ? 2 : (c.ones_neg ? 1 : 0);
-    const dim3 grid(tp.n_tiles), block(kTileThreads);
+    const dim3 grid(tile_count), block(kTileThreads);
 #define BHW_LAUNCH_TILE_M(NB, M)                                                                                         \
     do {                                                                                                                 \
         if (c.tab_dlog == 0)             BHW_LAUNCH((k_table_combine_tile<NB, M, 0>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
@@ -1480,6 +1645,121 @@ int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const Bhw
     else BHW_LAUNCH_TILE(1);
 #undef BHW_LAUNCH_TILE_M
 #undef BHW_LAUNCH_TILE
+    return finish(hipSuccess);
+}
+
+int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out)
+{
+    return bhwk_table_combine_tile_range(l, c, w, d_table, d_out, 0, 0);
+}
+
+// Kernel names of the table strategy's two passes for a resolved configuration (bhw_describe_plan: profilers, bench labels).
+// Mirrors the dispatch in bhwk_table_build / bhwk_table_combine_tile_range / bhwk_table_combine_fold.
+void bhwk_describe_table(const BhwCordicCfg &c, const BhwWinCfg &w, bool tiled, char *build, char *combine, size_t len)
+{
+    const uint32_t entries = 1u << (c.phi_width - 2 - c.z_shr);
+    const bool fits = (c.dat_width + c.out_shr <= 34);
+    const int fmt = c.tab_dlog == 0 ? 0 : c.tab_dlog == kPackLog ? 1 : 2;
+    if (fits && c.n_iter >= 7 && entries < (1u << 20) && c.tab_dlog == 0 && !c.tab_split) snprintf(build, len, "k_table_build_plain<%u>", c.n_iter);
+    else if (entries >= 64 && fits && c.n_iter >= 2) snprintf(build, len, "k_table_build_shared<%u,%d>", c.n_iter, fmt);
+    else snprintf(build, len, "k_table_build<%s>", c.wide ? "int64_t" : "int32_t");
+    const int mode = (w.combine != BHW_COMBINE_HLS) ? 2 : (c.ones_neg ? 1 : 0);
+    if (tiled) {
+        const int nb3 = (c.z_shr == 0 && w.n_terms > 3) ? 3 : 1, nb5 = (c.z_shr == 0 && w.n_terms > 5) ? 5 : 1;
+        snprintf(combine, len, "k_table_combine_tile<%d,%d,%d>", nb3 * nb5, mode, fmt);
+    } else if (c.tab_dlog == 0 && !c.tab_split) snprintf(combine, len, "k_table_combine_fold_t<%u,%d>", w.n_terms, mode);
+    else snprintf(combine, len, "k_table_combine_fold");
+}
+
+// Interleaved ownership (bhw_generate_part_device): the ring lanes of part `part` of `n_parts`, as runs of consecutive r.
+// Where the tile kernel applies the parts are contiguous ranges of its tiles, i.e. the plan's sibling runs (so a part can be
+// produced by the tile kernel over the full table or by the fused kernel, with the same ownership); elsewhere they are
+// contiguous ranges of the ring in 64-lane units.  Runs that wrap the ring are split; neighbouring parts overlap by the few
+// lanes the tile plan covers twice at its seams (identical values).
+int bhwk_part_runs(const BhwCordicCfg &c, const BhwWinCfg &w, uint32_t part, uint32_t n_parts, BhwFoldRun *runs, uint32_t *tile0, uint32_t *tile_count)
+{
+    const uint32_t H = 1u << (c.phi_width - 3);
+    *tile0 = *tile_count = 0;
+    if (n_parts < 1) n_parts = 1;
+    if (!bhwk_tile_applicable(c, w)) {
+        const uint32_t units = (H + 63u) >> 6;
+        const uint32_t a = (uint32_t)((uint64_t)units * part / n_parts) << 6, b = (uint32_t)((uint64_t)units * (part + 1u) / n_parts) << 6;
+        runs[0] = BhwFoldRun{a < H ? a : H, b < H ? b : H};
+        return runs[0].r_end > runs[0].r0 ? 1 : 0;
+    }
+    BhwTilePlan tp;
+    int nb;
+    uint32_t lanes;
+    make_tile_plan(c, w, tp, nb, lanes);
+    const uint32_t t0 = (uint32_t)((uint64_t)tp.n_tiles * part / n_parts), t1 = (uint32_t)((uint64_t)tp.n_tiles * (part + 1u) / n_parts);
+    *tile0 = t0;
+    *tile_count = t1 - t0;
+    if (t1 == t0) return 0;
+    const uint64_t len = (uint64_t)(t1 - t0) * lanes;
+    int n = 0;
+    for (int b = 0; b < nb; ++b) {
+        if (len >= H) { runs[0] = BhwFoldRun{0u, H}; return 1; }
+        const uint32_t start = (uint32_t)(((uint64_t)t0 * lanes + tp.offs[b]) & (H - 1u));
+        if (start + len <= H) runs[n++] = BhwFoldRun{start, (uint32_t)(start + len)};
+        else {
+            runs[n++] = BhwFoldRun{start, H};
+            runs[n++] = BhwFoldRun{0u, (uint32_t)(start + len - H)};
+        }
+    }
+    return n;
+}
+
+bool bhwk_fold_direct_applicable(const BhwCordicCfg &c)
+{
+    // rot_step's forms: |x| < 2^33 and a quarter circle <= 2^32; ring of at least one wave
+    return c.dat_width + c.out_shr <= 34 && c.phi_width >= 9 && c.phi_width <= 30 && c.n_iter >= 2;
+}
+
+int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const BhwFoldRun *runs, uint32_t n_runs, int32_t *d_out)
+{
+    if (!n_runs) return 0;
+    if (n_runs > (uint32_t)kFoldRunsMax || !bhwk_fold_direct_applicable(c)) return (int)hipErrorInvalidValue;
+    BHW_SET_DEVICE(l);
+    hipStream_t st = (hipStream_t)l.stream;
+    BhwFoldPlan plan;
+    memset(&plan, 0, sizeof plan);
+    for (uint32_t k = 0; k < 32; ++k) plan.lut[k] = (uint32_t)c.lut[k];
+    plan.x0 = c.x0;
+    plan.n_iter = c.n_iter;
+    plan.z_shr = c.z_shr;
+    plan.z_shl = c.z_shl;
+    plan.out_shr = c.out_shr;
+    plan.n_runs = n_runs;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_runs; ++i) total += runs[i].r_end - runs[i].r0;
+    // short launches: one wave per workgroup spreads the few waves over more CUs
+    const uint32_t block = total <= 64u * 1024u ? 64u : (uint32_t)kFoldBlock;
+    uint32_t wg = 0;
+    for (uint32_t i = 0; i < n_runs; ++i) {
+        plan.r0[i] = runs[i].r0;
+        plan.r_end[i] = runs[i].r_end;
+        plan.wg_first[i] = wg;
+        wg += (runs[i].r_end - runs[i].r0 + block - 1u) / block;
+    }
+    plan.wg_first[n_runs] = wg;
+    if (!wg) return 0;
+    const int mode = (w.combine != BHW_COMBINE_HLS) ? 2 : (c.ones_neg ? 1 : 0);
+    const dim3 grid(wg), blk(block);
+#define BHW_FD_NT(NT)                                                                                       \
+    do {                                                                                                    \
+        if (mode == 0)      BHW_LAUNCH((k_fold_direct<NT, 0>), grid, blk, 0, st, c, w, plan, d_out);        \
+        else if (mode == 1) BHW_LAUNCH((k_fold_direct<NT, 1>), grid, blk, 0, st, c, w, plan, d_out);        \
+        else                BHW_LAUNCH((k_fold_direct<NT, 2>), grid, blk, 0, st, c, w, plan, d_out);        \
+    } while (0)
+    switch (w.n_terms) {
+    case 2: BHW_FD_NT(2); break;
+    case 3: BHW_FD_NT(3); break;
+    case 4: BHW_FD_NT(4); break;
+    case 5: BHW_FD_NT(5); break;
+    case 7: BHW_FD_NT(7); break;
+    default: return (int)hipErrorInvalidValue;
+    }
+#undef BHW_FD_NT
     return finish(hipSuccess);
 }
 

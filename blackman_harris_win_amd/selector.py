@@ -90,6 +90,19 @@ def generate(params, n0, count, *, device=None, out=None, algo=B.ALGO_AUTO, work
     return out
 
 
+def generate_part(params, part, n_parts, window, *, algo=B.ALGO_AUTO, workspace=None, event_after_build=None,
+                  table_format=B.TABLE_BEST):
+    """Interleaved ownership (bhw_generate_part_device): writes the coefficients part `part` of `n_parts` owns into `window`,
+    a full-length (2^phi_width) int32 CUDA tensor; every other element is left untouched.  binding.part_segments lists them."""
+    torch = _torch()
+    dev = _check_out(torch, window, 1 << params.phi_width, "window")
+    ex = _exec(algo, workspace, event_after_build, table_format)
+    with torch.cuda.device(dev):
+        B.check(B.lib().bhw_generate_part_device(ctypes.byref(params), dev, _stream_ptr(torch, dev), int(part), int(n_parts),
+                                                  ctypes.c_void_p(window.data_ptr()), ctypes.byref(ex)))
+    return window
+
+
 def apply(params, x, *, n0=0, shift=None, out=None):
     """Fused apply: y[i] = (x[i] * w[n0+i]) >> shift without materialising w (bhw_apply_device).
     `shift` defaults to dat_width - 1 (unit gain for a full-scale window)."""
@@ -221,6 +234,22 @@ class WinSelector:
         """One full period from phase 0."""
         return generate(self.params, 0, self.length, device=self.device, out=out, algo=algo)
 
-    def shard(self, rank, world_size, out=None, algo=B.ALGO_AUTO):
-        n0, count = shard_range(self.length, rank, world_size)
-        return generate(self.params, n0, count, device=self.device, out=out, algo=algo)
+    def shard(self, rank, world_size, out=None, algo=B.ALGO_AUTO, layout="contiguous"):
+        """This rank's share of ONE window over `world_size` devices, no collective.
+        layout "contiguous": the index range shard_range(N, rank, world_size), returned as a tensor of that length.
+        layout "interleaved": the ownership part (rank, world_size) of include/bhw.h -- ring lanes with their eight quadrant /
+        half-period images, so the folds still share CORDIC work; written into `out`, a full-length window buffer (allocated
+        when None: elements this rank does not own stay uninitialised), which is returned; self.segments(...) lists them."""
+        if layout == "contiguous":
+            n0, count = shard_range(self.length, rank, world_size)
+            return generate(self.params, n0, count, device=self.device, out=out, algo=algo)
+        if layout != "interleaved":
+            raise ValueError("layout must be 'contiguous' or 'interleaved'")
+        if out is None:
+            torch = _torch()
+            out = torch.empty(self.length, dtype=torch.int32, device=f"cuda:{_dev_index(torch, self.device)}")
+        return generate_part(self.params, rank, world_size, out, algo=algo)
+
+    def segments(self, rank, world_size):
+        """[(n0, count), ...] owned by `rank` in the interleaved layout (host arithmetic, no GPU needed)."""
+        return B.part_segments(self.params, rank, world_size)

@@ -60,7 +60,10 @@ enum { BHW_WIN_HAMMING = 1, BHW_WIN_HANN = 2, BHW_WIN_BH3 = 3, BHW_WIN_BH4 = 4, 
 enum {
     BHW_ALGO_AUTO   = 0,
     BHW_ALGO_DIRECT = 1, /* one lane per coefficient, K-1 CORDIC chains per lane              */
-    BHW_ALGO_TABLE  = 2  /* first-quadrant CORDIC table built once per call, then gather-combine */
+    BHW_ALGO_TABLE  = 2, /* first-quadrant CORDIC table built once per call, then gather-combine */
+    BHW_ALGO_FUSED  = 3  /* whole periods in one launch, no table: one lane per eight coefficients (quadrant + half-period
+                            fold), shared rotation prefixes per wave; ragged ends take BHW_ALGO_DIRECT.  Falls back to
+                            BHW_ALGO_TABLE where it does not apply (34-bit+ CORDIC state, phi_width < 9)            */
 };
 
 enum {
@@ -138,6 +141,11 @@ int bhw_generate_device_ex(const bhw_params *p, int device, void *hip_stream,
 /* Device scratch the given call would need with `algo` (0 for the direct strategy). */
 uint64_t bhw_workspace_bytes(const bhw_params *p, uint64_t n0, uint64_t count, uint32_t algo);
 
+/* What bhw_generate_device_ex(p, ..., n0, count, ..., ex) would launch right now, as one line of text into buf (NUL-terminated,
+ * truncated to len): strategy, table format and the kernel names a profiler will show.  The table format of a configuration
+ * is settled on its first use (or by bhw_prepare_device); before that the line says "unverified".  Host arithmetic only. */
+int bhw_describe_plan(const bhw_params *p, uint64_t n0, uint64_t count, const bhw_exec *ex, char *buf, uint64_t len);
+
 /* Does every lazy step of later calls with `p` on (device, hip_stream) now: uploads the Taylor quarter-wave ROM
  * (taylor_sincos.vhd:91-111 builds it at elaboration), allocates the library-owned table scratch of this stream, and verifies
  * once, on the device, that the packed table formats are exact for this (model, phi_width, dat_width, precision) -- a property
@@ -146,6 +154,25 @@ uint64_t bhw_workspace_bytes(const bhw_params *p, uint64_t n0, uint64_t count, u
  * the same work inline (one synchronisation); during stream capture an unprepared Taylor call fails with BHW_ERR_HIP and an
  * unprepared table call uses the plain table format. */
 int bhw_prepare_device(const bhw_params *p, int device, void *hip_stream);
+
+/* Interleaved ownership of ONE window over several devices (every coefficient is an independent function of its
+ * index, src/bh_win_7term.vhd:176-197 | hls/windows/win_function.cpp:361-375).  Contiguous index shards -- n0 = g * N / G with
+ * bhw_generate_device -- cannot share CORDIC work between the quadrant images of a coefficient; an interleaved part can: part
+ * `part` of `n_parts` owns a set of lanes r of the ring [0, N/8) together with the eight coefficients r + h*N/8 + j*N/4 of each,
+ * so one first-quadrant CORDIC result still serves up to eight coefficients.  The ownership is a deterministic function of
+ * (phi_width, dat_width, model, n_terms, n_parts): bhw_part_segments lists it as sorted contiguous index segments (at most
+ * 256); the parts of one window cover [0, N) -- neighbouring parts may both own a few hundred coefficients at the seams of
+ * the internal tiling, with identical values.
+ * bhw_generate_part_device writes exactly the owned coefficients into d_window, the base of a full-length (2^phi_width)
+ * int32 buffer on `device`; all other elements are left untouched.  CORDIC source only.  No collective is involved: a
+ * consumer that wants the whole window on one device copies the segments (hipMemcpyPeerAsync). */
+typedef struct bhw_segment {
+    uint64_t n0;     /* first coefficient index */
+    uint64_t count;  /* coefficients            */
+} bhw_segment;
+int bhw_part_segments(const bhw_params *p, uint32_t part, uint32_t n_parts, bhw_segment *segs, uint32_t capacity, uint32_t *n_segs);
+int bhw_generate_part_device(const bhw_params *p, int device, void *hip_stream, uint32_t part, uint32_t n_parts,
+                             int32_t *d_window, const bhw_exec *ex);
 
 /* Fused apply (the step after the path in every consumer -- the window multiplies the samples in
  * front of an FFT).  d_y[i] = (d_x[i] * w[n0+i]) >> shift with the exact 64-bit product (as int_multNxN_dsp48,

@@ -90,16 +90,17 @@ def test_prepare_then_graph_capture_without_workspace(torch):
     import blackman_harris_win_amd as bhw
     st = torch.cuda.Stream()
     pt = B.make_params(7, 22, 30)
-    py = B.make_params(3, 16, 27, combine=B.COMBINE_VHDL, sin_type=B.SIN_TAYLOR, lut_size=7)   # a ROM no other test uploads
+    # lut_size 14: a ROM no other test uploads (the fuzz slice draws at most 13)
+    py = B.make_params(3, 20, 29, combine=B.COMBINE_VHDL, sin_type=B.SIN_TAYLOR, lut_size=14)
     want_t = O.generate_mt(O.from_bhw(pt), 0, 1 << 22)
     with torch.cuda.stream(st):
         out_t = torch.zeros(1 << 22, dtype=torch.int32, device="cuda")
-        out_y = torch.zeros(1 << 16, dtype=torch.int32, device="cuda")
+        out_y = torch.zeros(1 << 15, dtype=torch.int32, device="cuda")
         st.synchronize()
         g_bad = torch.cuda.CUDAGraph()
         with pytest.raises(B.BhwError) as ei:
             with torch.cuda.graph(g_bad, stream=st):
-                bhw.generate(py, 0, 1 << 16, out=out_y)
+                bhw.generate(py, 777, 1 << 15, out=out_y)
         assert ei.value.code == -3 and "bhw_prepare_device" in ei.value.detail
         del g_bad
         bhw.prepare(pt)
@@ -107,14 +108,14 @@ def test_prepare_then_graph_capture_without_workspace(torch):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=st):
             bhw.generate(pt, 0, 1 << 22, out=out_t)
-            bhw.generate(py, 0, 1 << 16, out=out_y)
+            bhw.generate(py, 777, 1 << 15, out=out_y)
         for _ in range(2):
             out_t.zero_()
             out_y.zero_()
             graph.replay()
             st.synchronize()
             assert np.array_equal(out_t.cpu().numpy(), want_t)
-            assert np.array_equal(out_y.cpu().numpy(), O.generate(O.from_bhw(py), 0, 1 << 16))
+            assert np.array_equal(out_y.cpu().numpy(), O.generate_mt(O.from_bhw(py), 777, 1 << 15))
 
 
 def _dbg():

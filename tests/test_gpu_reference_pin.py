@@ -72,11 +72,19 @@ def test_golden_c3cpp_is_reference_made(golden):
 
 
 # ---- (2a) window_test.cpp's criterion on the HIP output ---------------------------------------------------------------
-def window_rule(torch, got, gold, w, max_lsb):
+def window_rule(torch, got, gold, w, max_lsb, quirk_frac=0.0):
     n = got.numel()
     err = got.to(torch.float64) - gold
     # the HLS model's (win_t) store wraps (Hann at 10/24 peaks at 2^23): compare modulo 2^W as tests/test_oracle.py does
     err = torch.remainder(err + 2.0 ** (w - 1), 2.0 ** w) - 2.0 ** (w - 1)
+    if quirk_frac:
+        # Taylor feeder, DATA_WIDTH > 18: tay1_order.vhd:602-616 replaces a negative cos' / sin' by 2^(W-1) - 1.  Meant for the
+        # overflow of sin' near the quadrant's end, it also fires where cos' = C - floor(m S / 2^X) dips a few LSB below zero
+        # there, so a handful of samples per period read full scale instead of ~0 -- upstream behaviour, reproduced bit for bit
+        # (the oracle comparison proves that).  Those samples are counted, bounded and left out of the criterion.
+        bad = err.abs() > max_lsb
+        assert int(bad.sum()) <= quirk_frac * n, (int(bad.sum()), n)
+        err = torch.where(bad, torch.zeros_like(err), err)
     acc_err = float(torch.sqrt((err * err).sum())) / n                 # window_test.cpp:198,209
     assert acc_err < 10, acc_err                                       # :216
     assert float(err.abs().max()) <= max_lsb, float(err.abs().max())   # stricter than the reference: a few LSB everywhere
@@ -126,7 +134,7 @@ def test_reference_window_rule_on_gpu_output_taylor(torch, name, win, pw, w, L):
     div = 2.0 if win in (1, 2) else 4.0
     gold = float_window(torch, win, pw, (2.0 ** (w - shift) - 1.0) / div)
     taylor_err = 2.0 ** (w - 1) * (np.pi / 2 ** (L + 1)) ** 2 / 2
-    window_rule(torch, got, gold, w, max_lsb=8 + 1.2 * taylor_err * sum(COEF[win][1:]) / div)
+    window_rule(torch, got, gold, w, max_lsb=8 + 1.2 * taylor_err * sum(COEF[win][1:]) / div, quirk_frac=2e-5 if w > 18 else 0.0)
 
 
 # ---- (2b) cordic_test.cpp's criterion on the HIP output ---------------------------------------------------------------
@@ -160,5 +168,11 @@ def test_reference_cordic_rule_on_gpu_output_taylor(torch, pw, w, L):
     es = (s.to(torch.float64) - amp * torch.sin(i)).abs()
     ec = (c.to(torch.float64) - amp * torch.cos(i)).abs()
     tol = 4 + 1.2 * amp * (np.pi / 2 ** (L + 1)) ** 2 / 2
+    if w > 18:
+        # tay1_order.vhd:602-616: a first-quadrant value that dips below zero next to the quadrant's end is replaced by full scale
+        # (see window_rule); counted, bounded, and left out of the mean
+        bad = (es > tol) | (ec > tol)
+        assert int(bad.sum()) <= 2e-5 * n, int(bad.sum())
+        es, ec = torch.where(bad, torch.zeros_like(es), es), torch.where(bad, torch.zeros_like(ec), ec)
     assert float(es.sum()) / n < max(10, tol) and float(ec.sum()) / n < max(10, tol)
     assert float(es.max()) <= tol and float(ec.max()) <= tol

@@ -1,0 +1,200 @@
+"""Interleaved ownership parts (include/bhw.h: bhw_part_segments / bhw_generate_part_device).
+CPU: the segment lists are host arithmetic -- they must tile the window.  GPU: parts assembled on one device reproduce the
+window bit for bit, whichever kernel produced them, and write nothing they do not own."""
+import ctypes
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from blackman_harris_win_amd import binding as B
+
+CONFIGS = [(7, 26, 32, B.MODEL_HLS), (4, 22, 24, B.MODEL_CPP), (5, 23, 30, B.MODEL_VHDL), (3, 22, 28, B.MODEL_HLS),
+           (7, 24, 16, B.MODEL_CPP), (7, 16, 32, B.MODEL_HLS), (4, 20, 24, B.MODEL_HLS), (2, 9, 16, B.MODEL_HLS), (7, 30, 32, B.MODEL_HLS)]
+
+
+@pytest.mark.parametrize("n_parts", [1, 2, 3, 4, 8, 64])
+@pytest.mark.parametrize("win,pw,w,model", CONFIGS)
+def test_part_segments_tile_the_window(win, pw, w, model, n_parts):
+    p = B.make_params(win, pw, w, model=model)
+    n = 1 << pw
+    events = []
+    owned = 0
+    for part in range(n_parts):
+        segs = B.part_segments(p, part, n_parts)
+        assert segs == sorted(segs) and len(segs) <= 256
+        for (a, ca), (b, _) in zip(segs, segs[1:]):
+            assert a + ca < b                                   # merged: neither touching nor overlapping inside one part
+        for n0, cnt in segs:
+            assert cnt > 0 and 0 <= n0 and n0 + cnt <= n
+            events.append((n0, 1))
+            events.append((n0 + cnt, -1))
+            owned += cnt
+        # closed under the eight images: the set of ring lanes is the same in every eighth of the window
+        ring = n // 8
+        lanes = [[] for _ in range(8)]
+        for n0, cnt in segs:                                    # cut at the eighths (merging may have joined images)
+            while cnt:
+                img = n0 // ring
+                take = min(cnt, (img + 1) * ring - n0)
+                if lanes[img] and lanes[img][-1][0] + lanes[img][-1][1] == n0 - img * ring:
+                    lanes[img][-1] = (lanes[img][-1][0], lanes[img][-1][1] + take)
+                else:
+                    lanes[img].append((n0 - img * ring, take))
+                n0, cnt = n0 + take, cnt - take
+        assert all(x == lanes[0] for x in lanes[1:])
+    # coverage: every index owned at least once; double ownership (tile seams) stays below 1 %
+    events.sort()
+    depth, pos = 0, 0
+    for x, d in events:
+        if x > pos:
+            assert depth >= 1, (pos, x)
+            pos = x
+        depth += d
+    assert pos == n and owned >= n and owned <= n + max(n // 100, 8 * 960 * n_parts)
+
+
+def test_part_argument_errors():
+    L = B.lib()
+    p = B.make_params(7, 20, 32)
+    n = ctypes.c_uint32()
+    assert L.bhw_part_segments(ctypes.byref(p), 2, 2, None, 0, ctypes.byref(n)) == -1          # part >= n_parts
+    assert L.bhw_part_segments(ctypes.byref(p), 0, 0, None, 0, ctypes.byref(n)) == -1
+    assert L.bhw_part_segments(ctypes.byref(p), 0, 65, None, 0, ctypes.byref(n)) == -1
+    assert L.bhw_part_segments(ctypes.byref(p), 0, 2, None, 0, None) == -1
+    assert L.bhw_part_segments(ctypes.byref(p), 0, 2, None, 0, ctypes.byref(n)) == 0 and n.value == 8   # count query
+    segs = (B.BhwSegment * 4)()
+    assert L.bhw_part_segments(ctypes.byref(p), 0, 2, segs, 4, ctypes.byref(n)) == -1          # capacity too small
+    pt = B.make_params(3, 12, 16, sin_type=B.SIN_TAYLOR)
+    assert L.bhw_part_segments(ctypes.byref(pt), 0, 2, None, 0, ctypes.byref(n)) == -2          # CORDIC source only
+    ps = B.make_params(4, 8, 16)
+    assert L.bhw_part_segments(ctypes.byref(ps), 0, 2, None, 0, ctypes.byref(n)) == -2          # ring shorter than a wave
+
+
+# ---- GPU ----------------------------------------------------------------------------------------------------------------
+def _md5(a):
+    return hashlib.md5(np.ascontiguousarray(a, dtype="<i4").tobytes()).hexdigest()
+
+
+SENTINEL = -0x5A5A5A5B
+
+
+def assemble(torch, bhw, p, n_parts, algo, check_untouched=True):
+    n = 1 << p.phi_width
+    window = torch.full((n,), SENTINEL, dtype=torch.int32, device="cuda")
+    for part in range(n_parts):
+        if check_untouched:
+            mine = torch.full((n,), SENTINEL, dtype=torch.int32, device="cuda")
+            bhw.generate_part(p, part, n_parts, mine, algo=algo)
+            owned = torch.zeros(n, dtype=torch.bool, device="cuda")
+            for n0, cnt in B.part_segments(p, part, n_parts):
+                owned[n0:n0 + cnt] = True
+            # exactly the owned coefficients were written (the sentinel is not a value these windows take)
+            assert bool(((mine != SENTINEL) == owned).all()), (part, n_parts, algo)
+            window = torch.where(owned, mine, window)
+            del mine, owned
+        else:
+            bhw.generate_part(p, part, n_parts, window, algo=algo)
+    return window
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_parts,algo", [(2, B.ALGO_AUTO), (4, B.ALGO_AUTO), (8, B.ALGO_AUTO), (8, B.ALGO_TABLE), (3, B.ALGO_FUSED)])
+def test_c3_window_from_interleaved_parts(golden, n_parts, algo):
+    """BASELINE C5: the 2^26-point BH-7 / 32-bit window assembled on one device from G ownership parts equals the C3 golden
+    (per-shard md5), for the strategy AUTO picks per part size (table + tile sub-range for G = 2, 4; fused for G = 8) and for
+    the other one."""
+    import torch
+    import blackman_harris_win_amd as bhw
+    p = B.make_params(7, 26, 32)
+    window = assemble(torch, bhw, p, n_parts, algo, check_untouched=(n_parts == 8 and algo == B.ALGO_AUTO))
+    e = golden["C3_bh7_26_32"]
+    for g in range(8):
+        sh = window[g << 23:(g + 1) << 23]
+        assert int(sh.sum(dtype=torch.int64)) == e["shards"][g]["sum"], (g, n_parts, algo)
+        assert _md5(sh.cpu().numpy()) == e["shards"][g]["md5"], (g, n_parts, algo)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("win,pw,w,model,combine,n_parts", [
+    (4, 22, 24, B.MODEL_CPP, B.COMBINE_HLS, 3), (7, 22, 30, B.MODEL_VHDL, B.COMBINE_VHDL, 5), (5, 16, 24, B.MODEL_HLS, B.COMBINE_HLS, 4),
+    (3, 23, 28, B.MODEL_HLS, B.COMBINE_VHDL, 2), (7, 24, 16, B.MODEL_CPP, B.COMBINE_HLS, 8), (2, 12, 16, B.MODEL_VHDL, B.COMBINE_VHDL, 7),
+    (7, 20, 32, B.MODEL_HLS, B.COMBINE_HLS, 8), (7, 22, 32, B.MODEL_VHDL, B.COMBINE_HLS, 64)])
+def test_parts_match_oracle(win, pw, w, model, combine, n_parts):
+    import torch
+    import blackman_harris_win_amd as bhw
+    p = B.make_params(win, pw, w, model=model, combine=combine, precision=2 if model == B.MODEL_VHDL else 1)
+    want = O.generate_mt(O.from_bhw(p), 0, 1 << pw)
+    for algo in (B.ALGO_AUTO, B.ALGO_FUSED, B.ALGO_TABLE):
+        if algo == B.ALGO_TABLE and pw < 22:
+            with pytest.raises(B.BhwError):                         # no tile plan below 2^22: only the fused kernel makes parts
+                bhw.generate_part(p, 0, n_parts, torch.empty(1 << pw, dtype=torch.int32, device="cuda"), algo=algo)
+            continue
+        got = assemble(torch, bhw, p, n_parts, algo, check_untouched=(algo == B.ALGO_AUTO))
+        assert np.array_equal(got.cpu().numpy(), want), (algo,)
+
+
+@pytest.mark.gpu
+def test_win_selector_interleaved_shards():
+    import torch
+    from blackman_harris_win_amd import WinSelector
+    sel = WinSelector(PHI_WIDTH=18, DAT_WIDTH=24, WIN_TYPE="BH5TERM")
+    full = sel.window()
+    buf = torch.zeros(sel.length, dtype=torch.int32, device="cuda")
+    for r in range(4):
+        out = sel.shard(r, 4, out=buf, layout="interleaved")
+        assert out is buf
+        for n0, cnt in sel.segments(r, 4):
+            assert bool((buf[n0:n0 + cnt] == full[n0:n0 + cnt]).all())
+    assert bool((buf == full).all())
+    with pytest.raises(ValueError):
+        sel.shard(0, 4, layout="striped")
+
+
+# ---- the fused kernel as a strategy of plain generation -------------------------------------------------------------------
+FUSED_CASES = []
+for _model in (B.MODEL_HLS, B.MODEL_CPP, B.MODEL_VHDL):
+    for _combine in (B.COMBINE_HLS, B.COMBINE_VHDL):
+        for _win, _pw, _w in [(1, 9, 16), (2, 12, 24), (3, 13, 12), (4, 16, 24), (5, 14, 30), (7, 15, 32), (7, 12, 31), (4, 10, 8),
+                              (7, 18, 18), (5, 17, 13), (7, 20, 16), (4, 20, 24)]:
+            if _model == B.MODEL_HLS and _pw > _w + 2:
+                continue
+            FUSED_CASES.append((_model, _combine, _win, _pw, _w))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,combine,win,pw,w", FUSED_CASES)
+def test_fused_window_matches_oracle(model, combine, win, pw, w):
+    import blackman_harris_win_amd as bhw
+    prec = 1 + (pw + w) % 2 if model == B.MODEL_VHDL else 1
+    p = B.make_params(win, pw, w, model=model, combine=combine, precision=prec)
+    n = 1 << pw
+    po = O.from_bhw(p)
+    want = O.generate_mt(po, 0, n)
+    assert np.array_equal(bhw.generate(p, 0, n, algo=B.ALGO_FUSED).cpu().numpy(), want)
+    # head + two periods (the second a replica) + tail: direct kernel on the ragged ends
+    n0, cnt = 3 * n - 1234 % n, 2 * n + 4321
+    got = bhw.generate(p, n0, cnt, algo=B.ALGO_FUSED).cpu().numpy()
+    assert np.array_equal(got, np.resize(np.roll(want, -(n0 % n)), cnt))
+
+
+@pytest.mark.gpu
+def test_fused_with_wrapping_weights_apply_and_wide_fallback():
+    import torch
+    import blackman_harris_win_amd as bhw
+    rng = np.random.default_rng(5)
+    for win, pw, w, combine in [(7, 14, 30, B.COMBINE_HLS), (5, 13, 24, B.COMBINE_VHDL), (2, 12, 32, B.COMBINE_VHDL), (7, 16, 32, B.COMBINE_VHDL)]:
+        aa = [int(v) for v in rng.integers(-(1 << (w - 1)), 1 << (w - 1), 7)]
+        p = B.make_params(win, pw, w, combine=combine, aa=aa)
+        assert np.array_equal(bhw.generate(p, 0, 1 << pw, algo=B.ALGO_FUSED).cpu().numpy(), O.generate_mt(O.from_bhw(p), 0, 1 << pw))
+    # fused apply through the fused kernel: three periods of samples
+    p = B.make_params(7, 14, 32)
+    n = 1 << 14
+    x = torch.randint(-(1 << 31), (1 << 31) - 1, (3 * n,), dtype=torch.int32, device="cuda")
+    y = bhw.apply(p, x, shift=31)
+    wv = torch.from_numpy(O.generate_mt(O.from_bhw(p), 0, n)).cuda().repeat(3).to(torch.int64)
+    assert bool((((x.to(torch.int64) * wv) >> 31).to(torch.int32) == y).all())
+    # 36-bit CORDIC state (VHDL model, PRECISION 4 at 32 bits): the fused kernel does not apply, FUSED falls back to the table
+    p = B.make_params(4, 14, 32, model=B.MODEL_VHDL, precision=4)
+    assert np.array_equal(bhw.generate(p, 0, 1 << 14, algo=B.ALGO_FUSED).cpu().numpy(), O.generate_mt(O.from_bhw(p), 0, 1 << 14))

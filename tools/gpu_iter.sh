@@ -4,7 +4,7 @@
 tag=${1:-iter}; shift
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -k 10 600 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_$tag.log 2>&1
+timeout -k 10 900 python -m pytest tests -m gpu -x -q --durations=15 > gpurun_out/pytest_$tag.log 2>&1
 rc=$?; tail -3 gpurun_out/pytest_$tag.log
 [ $rc -ne 0 ] && { grep -E "^(FAILED|ERROR|E )" gpurun_out/pytest_$tag.log | head -20; exit $rc; }
 rm -rf gpurun_out/prof_$tag
