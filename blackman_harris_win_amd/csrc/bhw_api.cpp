@@ -527,6 +527,8 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
     };
     auto period = [&](uint64_t off) -> int {
         if (apply_x) w.apply_x = apply_x + off;
+        // dropped phase bits: consecutive coefficients repeat table entries -- the run-length kernel works per breakpoint
+        if (bhwk_runlength_applicable(c, w, d_out + off)) return bhwk_runlength_window(l, c, w, (const int32_t *)ws, d_out + off);
         return tiled ? bhwk_table_combine_tile(l, c, w, (const int32_t *)ws, d_out + off)
                      : bhwk_table_combine_fold(l, c, w, (const int32_t *)ws, d_out + off);
     };

@@ -91,6 +91,9 @@ void bhwk_describe_table(const BhwCordicCfg &c, const BhwWinCfg &w, bool tiled, 
 // tiles [tile0, tile0 + tile_count) of the tile plan only (tile_count 0: the whole ring)
 int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out,
                                   uint32_t tile0, uint32_t tile_count);
+// Run-length kernel: whole period of a configuration that drops phase bits (z_shr > 0), over the plain natural table
+bool bhwk_runlength_applicable(const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_out);
+int bhwk_runlength_window(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out);
 // Fused fold kernel (no table): for every ring lane r of the runs, the eight coefficients r + h*N/8 + j*N/4 into the
 // full-window buffer d_out.  At most 32 runs.
 struct BhwFoldRun { uint32_t r0, r_end; };

@@ -889,8 +889,7 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
 // per even harmonic -- 9 chains for 8 coefficients of a 7-term window instead of 48 in the direct kernel.  The 64 lanes of a
 // wave are consecutive r, so for every chain their leaves are equally spaced in angle and share a rotation prefix exactly as
 // the 64-leaf groups of k_table_build_shared do: phase 1 runs the (waves x chains) shared prefixes, one lane each, and parks
-// them in LDS; phase 2 is one lane per r.  Rotation count is a run-time bound on the unrolled steps (scalar guards), so one
-// instance serves every width.
+// them in LDS; phase 2 is one lane per r.  The rotation count is a run-time loop bound, so one instance serves every width.
 //
 // Used for (a) short whole windows (2^9 .. ~2^20 coefficients), where the table strategy is two dependent launches around a
 // table round trip, and (b) interleaved ownership parts of a long window (bhw_generate_part_device): a device that owns 1/G of
@@ -902,7 +901,7 @@ constexpr int kFoldRunsMax = 32;
 constexpr int kFoldBlock = 256;
 
 struct BhwFoldPlan {
-    uint32_t lut[32];                        // rescaled ROM as 32-bit words (quarter circle <= 2^32)
+    uint32_t lut[34];                        // rescaled ROM as 32-bit words (quarter circle <= 2^32); [32], [33] = 0: the loop reads one ahead
     int64_t  x0;
     uint32_t n_iter, z_shr, z_shl, out_shr;
     uint32_t n_runs, pad;
@@ -916,13 +915,41 @@ __host__ __device__ constexpr int fold_chains(int n_terms)      // first-quadran
     return n_terms == 2 ? 2 : n_terms == 3 ? 3 : n_terms == 4 ? 5 : n_terms == 5 ? 6 : 9;
 }
 
-// Remaining rotations of one chain from rotation k0 on: fully unrolled (immediate shifts, ROM words as scalar kernel
-// arguments), k0 and n_iter wave-uniform, so every guard is a scalar compare-and-branch.
+// Remaining rotations of one chain, k0 <= k < n_iter, as a rolled loop on a scalar counter: k0 and n_iter are wave-uniform, the
+// shift amount of v_alignbit_b32 and the ROM word (s_load from the kernel arguments, fetched one rotation ahead) are scalar
+// operands, so a rotation is the same 8 vector instructions as the unrolled rot_step plus ~5 scalar ones.  (Unrolled with a
+// scalar guard per rotation the kernel carried ~6 scalar instructions for every one of the 31 possible rotations of every
+// chain, executed or not -- more scalar than vector work, and the scalar unit is shared by the CU's four SIMDs.)
+__device__ __forceinline__ void rot_step_dyn(int64_t &x, int64_t &y, int32_t &z, int k, uint32_t lutk, bool mad24)
+{
+    const int32_t m = z >> 31;
+    const int32_t sg = m | 1;
+    const int32_t nsg = -sg;
+    int32_t ys = (int32_t)__builtin_amdgcn_alignbit((uint32_t)((uint64_t)y >> 32), (uint32_t)y, (uint32_t)k);   // lo32(y >> k), 1 <= k <= 31
+    int32_t xs = (int32_t)__builtin_amdgcn_alignbit((uint32_t)((uint64_t)x >> 32), (uint32_t)x, (uint32_t)k);
+    asm volatile("" : "+v"(ys), "+v"(xs));
+    x += (int64_t)nsg * (int64_t)ys;
+    y += (int64_t)sg * (int64_t)xs;
+    if (mad24) z += __mul24(nsg, (int32_t)lutk);
+    else       z = (int32_t)((uint32_t)z - lutk + ((2u * lutk) & (uint32_t)m));
+}
+
 __device__ __forceinline__ void chain_from(int64_t &x, int64_t &y, int32_t &z, int k0, int n_iter, const BhwFoldPlan &plan)
 {
-#pragma unroll
-    for (int k = 1; k < 32; ++k)
-        if (k >= k0 && k < n_iter) rot_step(x, y, z, k, plan.lut[k]);
+    int k = k0;                                                   // 1 <= k0 <= 20, n_iter <= 32
+    uint32_t cur = plan.lut[k];
+#pragma unroll 1
+    for (; k < n_iter && k < kMad24From; ++k) {                   // the first rotations: ROM words of 24 bits and more
+        const uint32_t nxt = plan.lut[k + 1];
+        rot_step_dyn(x, y, z, k, cur, false);
+        cur = nxt;
+    }
+#pragma unroll 1
+    for (; k < n_iter; ++k) {
+        const uint32_t nxt = plan.lut[k + 1];
+        rot_step_dyn(x, y, z, k, cur, true);
+        cur = nxt;
+    }
 }
 
 template <int NTERMS, int MODE>
@@ -1027,6 +1054,118 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwCordicCfg cfg, Bh
             else v = (int32_t)((uint32_t)acc[h][j] << (32u - W)) >> (32u - W);         // (win_t)(...) wrap to W bits
             emit(win, out, (uint64_t)(r + (uint32_t)h * H) + (uint64_t)j * E, v);
         }
+}
+
+// ---------------------------------------------------------------------------------------
+// Run-length kernel: whole periods of configurations that drop phase bits (z_shr > 0).
+//
+// Models A and C discard the low PW - W phase bits before the rotation (cpp/cordic_sincos.cpp:31-36, src/cordic_dds.vhd:159-162),
+// so only 2^(W-2) first-quadrant results exist however long the window is (2^14 pairs = 128 KiB at 16 bits: L2-resident) and
+// harmonic K of consecutive coefficients reads the SAME table entry for 2^z_shr / K of them in a row.  The coefficient stream
+// is therefore piecewise constant between "breakpoints" where some harmonic steps to its next entry, and a lane that owns a
+// run of consecutive ring positions does full work (gather, products, quadrant rotation) only twice per harmonic -- at the
+// two ends of its run -- and O(1) work per breakpoint in between:
+//   thread   = kRlRun = 16 consecutive ring lanes r (times the eight quadrant / half-period images);
+//   setup    : per chain (harmonic K, image h) the rotated term candidates at r_first and r_last and the position i_K of the
+//              one breakpoint in between (at most one while (NTERMS-1) * 16 <= 2^z_shr); delta_K = terms(last) - terms(first);
+//   sweep    : i = 0 .. 15: acc += delta_K where i == i_K (a wave-wide vote skips harmonics nobody steps at this i);
+//   output   : 16 values per image go through a swizzled LDS tile so that every store instruction writes 1 KiB of
+//              consecutive addresses (16 bytes per lane).
+// About 10 VALU instructions per coefficient instead of ~35, so these configurations run at the store rate.
+// All sums are plain int32: HLS rule modulo 2^32 as in the tile kernel; VHDL rule needs W + 2 <= 30 bits (z_shr > 0 means
+// W < PW <= 30 anyway; the launcher checks).
+// ---------------------------------------------------------------------------------------
+constexpr int kRlRun = 16;
+constexpr int kRlBlock = 128;
+
+// LDS tile of one (wave, image): 1024 values as 256 granules of 16 bytes, granule index XOR-swizzled inside rows of eight
+// so that both the producer pattern (granule 4*lane + c) and the consumer pattern (granule 64*s + lane) are conflict-free.
+__device__ __forceinline__ uint32_t rl_swizzle(uint32_t g) { return (g & ~7u) | ((g ^ (g >> 3)) & 7u); }
+
+template <int NTERMS, int MODE>
+__global__ __launch_bounds__(kRlBlock) void k_runlength_window(BhwCordicCfg cfg, BhwWinCfg win, const int2 *__restrict__ table,
+                                                              int32_t *__restrict__ out)
+{
+    __shared__ int4 tile[kRlBlock / 64][4][256];                          // [wave][image j][granule]: 16 KiB per wave
+    const uint32_t lq = cfg.phi_width - 2;
+    const uint32_t E = 1u << lq, emask = E - 1u, H = E >> 1;
+    const uint32_t W = cfg.dat_width, zs = cfg.z_shr, zmask = (1u << zs) - 1u;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t r_wave = (blockIdx.x * kRlBlock + (wave << 6)) * kRlRun;     // first ring lane of this wave's 1024
+    const uint32_t r0 = r_wave + lane * kRlRun;
+    constexpr uint32_t R1 = kRlRun - 1;
+
+    auto finish = [&](int32_t acc) -> int32_t {
+        if constexpr (MODE == 2) {
+            if constexpr (NTERMS == 2) { const int32_t S = wrap32(acc, W + 1); return wrap32((S >> 1) + (S & 1), W); }     // hamming_win.vhd:214-228
+            else { const int32_t S = wrap32(acc, W + 2); return wrap32((S >> 2) + ((S >> 1) & 1), W); }                     // bh_win_7term.vhd:409-435
+        } else return wrap32(acc, W);                                                                                      // win_function.cpp:375
+    };
+
+#pragma unroll 1
+    for (uint32_t h = 0; h < 2; ++h) {
+        int32_t acc[4] = {win.aa[0], win.aa[0], win.aa[0], win.aa[0]};
+        int32_t dlt[NTERMS][4];
+        uint32_t brk[NTERMS];
+#define BHW_RL_SETUP(K)                                                                                                  \
+        if constexpr (NTERMS > K) {                                                                                      \
+            const uint32_t hodd = (K & 1) ? h : 0u;                                                                      \
+            const uint32_t tha = (uint32_t)K * (r0 + hodd * H), thb = tha + (uint32_t)K * R1;   /* phases of the run's two ends */ \
+            const uint32_t ta = tha & emask, tb = thb & emask;                                                           \
+            const int2 csa = table[ta >> zs], csb = table[tb >> zs];                                                     \
+            int32_t sva[4], svb[4];                                                                                      \
+            tile_harmonic<K, MODE>(cfg, win.aa[K], W, csa, tha >> lq, sva);                                              \
+            tile_harmonic<K, MODE>(cfg, win.aa[K], W, csb, thb >> lq, svb);                                              \
+            /* first i at which the entry index (t >> z_shr, quadrant included) differs from the one at i = 0 */         \
+            brk[K] = ((zmask + 1u) - (ta & zmask) + (uint32_t)K - 1u) / (uint32_t)K;                                     \
+            constexpr int OFF = (K & 1) ? 0 : K / 2;                       /* even K: image h = 1 sits K/2 quadrants on */  \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                              \
+                const int ia = (j * K) & 3, ib = (j * K + OFF) & 3;                                                      \
+                int32_t va = h ? sva[ib] : sva[ia], vb = h ? svb[ib] : svb[ia];                                          \
+                if constexpr (MODE == 2 && (K & 1)) { va = -va; vb = -vb; }    /* VHDL rule: b_k enters with (-1)^k */    \
+                acc[j] += va;                                                                                            \
+                dlt[K][j] = vb - va;                                                                                     \
+            }                                                                                                            \
+        }
+        BHW_RL_SETUP(1) BHW_RL_SETUP(2) BHW_RL_SETUP(3) BHW_RL_SETUP(4) BHW_RL_SETUP(5) BHW_RL_SETUP(6)
+#undef BHW_RL_SETUP
+        // sweep the run; every four positions one 16-byte granule per image goes to the LDS tile
+#pragma unroll
+        for (int c4 = 0; c4 < kRlRun / 4; ++c4) {
+            int32_t v[4][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t i = (uint32_t)(c4 * 4 + e);
+                if (i) {
+#define BHW_RL_STEP(K)                                                                                                   \
+                    if constexpr (NTERMS > K) {                                                                          \
+                        if (__builtin_amdgcn_ballot_w64(brk[K] == i)) {            /* wave-uniform: usually nobody */   \
+                            const bool mine = brk[K] == i;                                                              \
+                            _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[j] += mine ? dlt[K][j] : 0;               \
+                        }                                                                                               \
+                    }
+                    BHW_RL_STEP(1) BHW_RL_STEP(2) BHW_RL_STEP(3) BHW_RL_STEP(4) BHW_RL_STEP(5) BHW_RL_STEP(6)
+#undef BHW_RL_STEP
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j][e] = finish(acc[j]);
+            }
+            const uint32_t g = rl_swizzle(4u * lane + (uint32_t)c4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tile[wave][j][g] = make_int4(v[j][0], v[j][1], v[j][2], v[j][3]);
+        }
+        __syncthreads();
+        // store instruction s of image j: lane l writes ring lanes r_wave + 256 s + 4 l .. + 3 (1 KiB per wave instruction)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int sgrp = 0; sgrp < 4; ++sgrp) {
+                const int4 d = tile[wave][j][rl_swizzle(64u * (uint32_t)sgrp + lane)];
+                const uint64_t idx = (uint64_t)(r_wave + 256u * (uint32_t)sgrp + 4u * lane + h * H) + (uint64_t)j * E;
+                *reinterpret_cast<int4 *>(out + idx) = d;
+            }
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1760,6 +1899,44 @@ int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg 
     default: return (int)hipErrorInvalidValue;
     }
 #undef BHW_FD_NT
+    return finish(hipSuccess);
+}
+
+// Run-length kernel: z_shr > 0, at most one entry step per harmonic inside a 16-lane run, ring a multiple of the workgroup's
+// 2048 lanes, plain natural table, 16-byte aligned output, no fused apply; VHDL rule in int32 needs W + 2 <= 30.
+bool bhwk_runlength_applicable(const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_out)
+{
+    if (c.z_shr == 0 || c.tab_dlog != 0 || c.tab_split != 0 || w.apply_x != nullptr) return false;
+    if (c.phi_width < 15 || c.phi_width > 30) return false;                       // ring (2^(PW-3)) >= 2048 lanes
+    if (((w.n_terms - 1u) * (uint32_t)kRlRun) > (1u << c.z_shr)) return false;
+    if (c.phi_width - 2u - c.z_shr < 2u) return false;                            // H a multiple of 2^z_shr
+    if (w.combine != BHW_COMBINE_HLS && c.dat_width > 28) return false;
+    return (((uintptr_t)d_out) & 15u) == 0;
+}
+
+int bhwk_runlength_window(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out)
+{
+    if (!bhwk_runlength_applicable(c, w, d_out)) return (int)hipErrorInvalidValue;
+    BHW_SET_DEVICE(l);
+    hipStream_t st = (hipStream_t)l.stream;
+    const uint32_t H = 1u << (c.phi_width - 3);
+    const dim3 grid(H / (kRlBlock * kRlRun)), block(kRlBlock);
+    const int mode = (w.combine != BHW_COMBINE_HLS) ? 2 : (c.ones_neg ? 1 : 0);
+#define BHW_RL_NT(NT)                                                                                                          \
+    do {                                                                                                                       \
+        if (mode == 0)      BHW_LAUNCH((k_runlength_window<NT, 0>), grid, block, 0, st, c, w, (const int2 *)d_table, d_out);   \
+        else if (mode == 1) BHW_LAUNCH((k_runlength_window<NT, 1>), grid, block, 0, st, c, w, (const int2 *)d_table, d_out);   \
+        else                BHW_LAUNCH((k_runlength_window<NT, 2>), grid, block, 0, st, c, w, (const int2 *)d_table, d_out);   \
+    } while (0)
+    switch (w.n_terms) {
+    case 2: BHW_RL_NT(2); break;
+    case 3: BHW_RL_NT(3); break;
+    case 4: BHW_RL_NT(4); break;
+    case 5: BHW_RL_NT(5); break;
+    case 7: BHW_RL_NT(7); break;
+    default: return (int)hipErrorInvalidValue;
+    }
+#undef BHW_RL_NT
     return finish(hipSuccess);
 }
 

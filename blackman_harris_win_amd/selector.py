@@ -17,11 +17,18 @@ _WIN_TYPES = {
 }
 
 
+_TORCH = None
+
+
 def _torch():
-    import torch
-    if not torch.cuda.is_available():
-        raise RuntimeError("no HIP device visible: the window generator runs only on the GPU (no CPU fallback)")
-    return torch
+    """torch, once a HIP device has been seen (cached: the per-call cost of the wrappers matters for short windows)."""
+    global _TORCH
+    if _TORCH is None:
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: the window generator runs only on the GPU (no CPU fallback)")
+        _TORCH = torch
+    return _TORCH
 
 
 def _stream_ptr(torch, device):
@@ -68,8 +75,7 @@ def prepare(params, *, device=None):
     without a caller workspace; otherwise optional."""
     torch = _torch()
     dev = _dev_index(torch, device)
-    with torch.cuda.device(dev):
-        B.check(B.lib().bhw_prepare_device(ctypes.byref(params), dev, _stream_ptr(torch, dev)))
+    B.check(B.lib().bhw_prepare_device(ctypes.byref(params), dev, _stream_ptr(torch, dev)))
 
 
 def generate(params, n0, count, *, device=None, out=None, algo=B.ALGO_AUTO, workspace=None, event_after_build=None,
@@ -84,9 +90,8 @@ def generate(params, n0, count, *, device=None, out=None, algo=B.ALGO_AUTO, work
     if workspace is not None and workspace.device.index != dev:
         raise ValueError("workspace must live on the output's device")
     ex = _exec(algo, workspace, event_after_build, table_format)
-    with torch.cuda.device(dev):
-        B.check(B.lib().bhw_generate_device_ex(ctypes.byref(params), dev, _stream_ptr(torch, dev), int(n0), int(count),
-                                                ctypes.c_void_p(out.data_ptr()), ctypes.byref(ex)))
+    B.check(B.lib().bhw_generate_device_ex(ctypes.byref(params), dev, _stream_ptr(torch, dev), int(n0), int(count),
+                                            ctypes.c_void_p(out.data_ptr()), ctypes.byref(ex)))
     return out
 
 
@@ -97,9 +102,8 @@ def generate_part(params, part, n_parts, window, *, algo=B.ALGO_AUTO, workspace=
     torch = _torch()
     dev = _check_out(torch, window, 1 << params.phi_width, "window")
     ex = _exec(algo, workspace, event_after_build, table_format)
-    with torch.cuda.device(dev):
-        B.check(B.lib().bhw_generate_part_device(ctypes.byref(params), dev, _stream_ptr(torch, dev), int(part), int(n_parts),
-                                                  ctypes.c_void_p(window.data_ptr()), ctypes.byref(ex)))
+    B.check(B.lib().bhw_generate_part_device(ctypes.byref(params), dev, _stream_ptr(torch, dev), int(part), int(n_parts),
+                                              ctypes.c_void_p(window.data_ptr()), ctypes.byref(ex)))
     return window
 
 
@@ -116,9 +120,8 @@ def apply(params, x, *, n0=0, shift=None, out=None):
         raise ValueError("out must live on x's device")
     if shift is None:
         shift = params.dat_width - 1
-    with torch.cuda.device(dev):
-        B.check(B.lib().bhw_apply_device(ctypes.byref(params), dev, _stream_ptr(torch, dev), int(n0), x.numel(),
-                                          ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()), int(shift)))
+    B.check(B.lib().bhw_apply_device(ctypes.byref(params), dev, _stream_ptr(torch, dev), int(n0), x.numel(),
+                                      ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()), int(shift)))
     return out
 
 
@@ -130,9 +133,8 @@ def generate_batched(params, frames, *, device=None, out=None):
     if out is None:
         out = torch.empty((int(frames), n), dtype=torch.int32, device=f"cuda:{dev}")
     dev = _check_out(torch, out, int(frames) * n)
-    with torch.cuda.device(dev):
-        B.check(B.lib().bhw_generate_batched_device(ctypes.byref(params), dev, _stream_ptr(torch, dev), int(frames),
-                                                     ctypes.c_void_p(out.data_ptr())))
+    B.check(B.lib().bhw_generate_batched_device(ctypes.byref(params), dev, _stream_ptr(torch, dev), int(frames),
+                                                 ctypes.c_void_p(out.data_ptr())))
     return out
 
 
@@ -142,9 +144,8 @@ def cordic(params, theta0, count, *, device=None):
     dev = _dev_index(torch, device)
     s = torch.empty(int(count), dtype=torch.int32, device=f"cuda:{dev}")
     c = torch.empty(int(count), dtype=torch.int32, device=f"cuda:{dev}")
-    with torch.cuda.device(dev):
-        B.check(B.lib().bhw_sincos_device(ctypes.byref(params), dev, _stream_ptr(torch, dev), int(theta0), int(count),
-                                           ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(c.data_ptr())))
+    B.check(B.lib().bhw_sincos_device(ctypes.byref(params), dev, _stream_ptr(torch, dev), int(theta0), int(count),
+                                       ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(c.data_ptr())))
     return s, c
 
 
@@ -160,10 +161,9 @@ def atan2(x, y, *, PRECISION=1, INPUT_WIDTH=20, ANGLE_WIDTH=16, out=None):
     if phi.dtype != torch.int32 or phi.device != x.device or phi.numel() != x.numel() or not phi.is_contiguous():
         raise ValueError("out must be a contiguous int32 tensor like x")
     p = B.BhwAtan2Params(ctypes.sizeof(B.BhwAtan2Params), PRECISION, INPUT_WIDTH, ANGLE_WIDTH)
-    with torch.cuda.device(dev):
-        B.check(B.lib().bhw_atan2_device(ctypes.byref(p), dev, _stream_ptr(torch, dev), x.numel(),
-                                          ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()),
-                                          ctypes.c_void_p(phi.data_ptr())))
+    B.check(B.lib().bhw_atan2_device(ctypes.byref(p), dev, _stream_ptr(torch, dev), x.numel(),
+                                      ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()),
+                                      ctypes.c_void_p(phi.data_ptr())))
     return phi
 
 

@@ -198,3 +198,37 @@ def test_fused_with_wrapping_weights_apply_and_wide_fallback():
     # 36-bit CORDIC state (VHDL model, PRECISION 4 at 32 bits): the fused kernel does not apply, FUSED falls back to the table
     p = B.make_params(4, 14, 32, model=B.MODEL_VHDL, precision=4)
     assert np.array_equal(bhw.generate(p, 0, 1 << 14, algo=B.ALGO_FUSED).cpu().numpy(), O.generate_mt(O.from_bhw(p), 0, 1 << 14))
+
+
+# ---- the run-length kernel (configurations that drop phase bits: models A / C at PW > W) -------------------------------
+RL_CASES = [(7, 26, 16, B.MODEL_CPP, B.COMBINE_HLS, 1), (7, 26, 16, B.MODEL_VHDL, B.COMBINE_HLS, 1), (7, 24, 14, B.MODEL_VHDL, B.COMBINE_VHDL, 2),
+            (4, 22, 16, B.MODEL_CPP, B.COMBINE_VHDL, 1), (5, 23, 12, B.MODEL_CPP, B.COMBINE_HLS, 1), (2, 22, 18, B.MODEL_VHDL, B.COMBINE_VHDL, 3),
+            (3, 22, 17, B.MODEL_CPP, B.COMBINE_HLS, 1), (7, 22, 15, B.MODEL_CPP, B.COMBINE_HLS, 1),     # z_shr 7: the tightest run (6 * 16 <= 128)
+            (7, 22, 16, B.MODEL_VHDL, B.COMBINE_VHDL, 1),                                               # z_shr 6: not applicable, tile kernel
+            (7, 28, 8, B.MODEL_CPP, B.COMBINE_HLS, 1), (7, 15, 8, B.MODEL_VHDL, B.COMBINE_HLS, 1)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("win,pw,w,model,combine,prec", RL_CASES)
+def test_runlength_kernel_matches_direct_and_oracle(win, pw, w, model, combine, prec):
+    """Whole periods with dropped phase bits go through k_runlength_window (TABLE strategy): identical to the DIRECT strategy
+    (one CORDIC chain per harmonic per coefficient) over the whole window, and to the oracle on head, seams and random slices."""
+    import torch
+    import blackman_harris_win_amd as bhw
+    rng = np.random.default_rng(pw * 64 + w)
+    aa = None if (pw + w) % 2 else [int(v) for v in rng.integers(-(1 << (w - 1)), 1 << (w - 1), 7)]
+    p = B.make_params(win, pw, w, model=model, combine=combine, precision=prec, aa=aa)
+    n = 1 << pw
+    got = bhw.generate(p, 0, n, algo=B.ALGO_TABLE)
+    ref = bhw.generate(p, 0, n, algo=B.ALGO_DIRECT)
+    assert bool((got == ref).all())
+    po = O.from_bhw(p)
+    for s0 in [0, n // 8 - 5000, n // 4 - 5000, n // 2 - 5000, n - 10000] + [int(v) for v in rng.integers(0, n - 10000, 3)]:
+        s0 = max(s0, 0)
+        assert np.array_equal(got[s0:s0 + 10000].cpu().numpy(), O.generate_mt(po, s0, 10000)), s0
+    # a ragged range around two periods: head and tail through the general gather kernel, the second period a replica
+    if pw <= 24:
+        two = bhw.generate(p, n - 777, 2 * n + 1500, algo=B.ALGO_TABLE)
+        assert bool((two[777:777 + n] == got).all()) and bool((two[777 + n:777 + 2 * n] == got).all())
+        assert bool((two[:777] == got[-777:]).all()) and bool((two[777 + 2 * n:] == got[:723]).all())
+    del got, ref
