@@ -32,6 +32,33 @@ def test_cpp_host_compiles_and_reports_errors_without_gpu(exe):
         assert r.returncode == 2 and b"no CPU path" in r.stderr     # fails loudly, no fallback
 
 
+def test_golden_dat_text(exe):
+    """golden_dat.dat of hls/windows/window_test.cpp (:196,201): the rounded float window, written by the C++ host mirror."""
+    import math
+    for sel, coef, shift in ((5, [0.3232153788877343, 0.4714921439576260, 0.1755341299601972, 0.0284969901061499, 0.0012613570882927], 2),
+                             (1, [0.5434783, 1 - 0.5434783], 1)):
+        r = subprocess.run([exe, "golden", str(sel), "10", "24"], capture_output=True, check=True)
+        i = np.arange(1024)
+        v = sum((-1) ** k * a * np.cos(k * 2.0 * i * math.pi / 1024) for k, a in enumerate(coef)) * (2.0 ** (24 - shift) - 1.0)
+        want = np.sign(v) * np.floor(np.abs(v) + 0.5)
+        got = np.array([int(x) for x in r.stdout.split()], dtype=np.int64)
+        assert r.stdout.endswith(b" \n") and len(got) == 1024
+        assert np.abs(got - want).max() <= 1                     # libm cos vs numpy cos: at most a rounding tie apart
+        assert (got != want).sum() <= 2
+
+
+@pytest.mark.gpu
+def test_dout_dat_and_golden_dat_pass_the_reference_rule(exe):
+    """The two files the testbench writes, as the C++ host mirror writes them (dout.dat from the GPU), put through its own
+    pass rule (window_test.cpp:198,209,216)."""
+    import math
+    for sel, pw, w in ((5, 10, 24), (7, 12, 16), (4, 14, 24)):
+        dout = np.array(subprocess.run([exe, "dout", str(sel), str(pw), str(w)], capture_output=True, check=True).stdout.split(), dtype=np.float64)
+        gold = np.array(subprocess.run([exe, "golden", str(sel), str(pw), str(w)], capture_output=True, check=True).stdout.split(), dtype=np.float64)
+        assert len(dout) == len(gold) == 1 << pw
+        assert math.sqrt(((dout - gold) ** 2).sum()) / (1 << pw) < 10
+
+
 @pytest.mark.gpu
 def test_coe_dat_byte_identical_to_reference(exe, golden):
     r = subprocess.run([exe, "coe", "14", "12"], capture_output=True, check=True)

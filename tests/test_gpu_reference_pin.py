@@ -71,6 +71,16 @@ def test_golden_c3cpp_is_reference_made(golden):
     assert golden["C3cpp_bh7_26_32"]["source"] == "reference"
 
 
+def taylor_cos_error(pw, w, L):
+    """Worst error of one Taylor-feeder cosine in LSB: the second-order remainder amp * d^2 / 2 over one ROM step d = pi / 2^(L+1),
+    plus the quantisation of the pi word of tay1_order.vhd:133 -- round(pi * 2^(17-STAGE)), STAGE = PW - L - 3, is 25 (pi * 8)
+    at PW 26 / L 9, half a percent off, and scales the whole first-order term."""
+    amp, step = 2.0 ** (w - 1), np.pi / 2 ** (L + 1)
+    e = 17 - (pw - L - 3)
+    rel = abs(round(np.pi * 2.0 ** e) / 2.0 ** e - np.pi) / np.pi if pw - L > 2 else 0.0
+    return amp * step ** 2 / 2 + amp * step * rel
+
+
 # ---- (2a) window_test.cpp's criterion on the HIP output ---------------------------------------------------------------
 def window_rule(torch, got, gold, w, max_lsb, quirk_frac=0.0):
     n = got.numel()
@@ -133,7 +143,7 @@ def test_reference_window_rule_on_gpu_output_taylor(torch, name, win, pw, w, L):
     got = bhw.generate(p, 0, 1 << pw)
     div = 2.0 if win in (1, 2) else 4.0
     gold = float_window(torch, win, pw, (2.0 ** (w - shift) - 1.0) / div)
-    taylor_err = 2.0 ** (w - 1) * (np.pi / 2 ** (L + 1)) ** 2 / 2
+    taylor_err = taylor_cos_error(pw, w, L)
     window_rule(torch, got, gold, w, max_lsb=8 + 1.2 * taylor_err * sum(COEF[win][1:]) / div, quirk_frac=2e-5 if w > 18 else 0.0)
 
 
@@ -167,7 +177,7 @@ def test_reference_cordic_rule_on_gpu_output_taylor(torch, pw, w, L):
     amp = 2.0 ** (w - 1) - 1.0
     es = (s.to(torch.float64) - amp * torch.sin(i)).abs()
     ec = (c.to(torch.float64) - amp * torch.cos(i)).abs()
-    tol = 4 + 1.2 * amp * (np.pi / 2 ** (L + 1)) ** 2 / 2
+    tol = 4 + 1.2 * taylor_cos_error(pw, w, L)
     if w > 18:
         # tay1_order.vhd:602-616: a first-quadrant value that dips below zero next to the quadrant's end is replaced by full scale
         # (see window_rule); counted, bounded, and left out of the mean
