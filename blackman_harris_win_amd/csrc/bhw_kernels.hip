@@ -916,8 +916,8 @@ __host__ __device__ constexpr int fold_chains(int n_terms)      // first-quadran
 }
 
 // Remaining rotations of one chain, k0 <= k < n_iter, as a rolled loop on a scalar counter: k0 and n_iter are wave-uniform, the
-// shift amount of v_alignbit_b32 and the ROM word (s_load from the kernel arguments, fetched one rotation ahead) are scalar
-// operands, so a rotation is the same 8 vector instructions as the unrolled rot_step plus ~5 scalar ones.  (Unrolled with a
+// shift amount of v_alignbit_b32 and the ROM word are scalar operands, so a rotation is the 8 vector instructions of the
+// unrolled rot_step, one v_readlane_b32 and ~3 scalar ones.  (Unrolled with a
 // scalar guard per rotation the kernel carried ~6 scalar instructions for every one of the 31 possible rotations of every
 // chain, executed or not -- more scalar than vector work, and the scalar unit is shared by the CU's four SIMDs.)
 __device__ __forceinline__ void rot_step_dyn(int64_t &x, int64_t &y, int32_t &z, int k, uint32_t lutk, bool mad24)
@@ -934,22 +934,18 @@ __device__ __forceinline__ void rot_step_dyn(int64_t &x, int64_t &y, int32_t &z,
     else       z = (int32_t)((uint32_t)z - lutk + ((2u * lutk) & (uint32_t)m));
 }
 
-__device__ __forceinline__ void chain_from(int64_t &x, int64_t &y, int32_t &z, int k0, int n_iter, const BhwFoldPlan &plan)
+// lutv: the rescaled ROM spread over the lanes of the wave (lane k holds lut[k]); v_readlane_b32 with the scalar rotation
+// counter fetches a word in a few cycles.  (As a scalar load from the kernel arguments every rotation waited ~100+ cycles for
+// its ROM word: short windows have too few waves to hide that, 9 us for a 2^16-point window.)
+__device__ __forceinline__ void chain_from(int64_t &x, int64_t &y, int32_t &z, int k0, int n_iter, uint32_t lutv)
 {
     int k = k0;                                                   // 1 <= k0 <= 20, n_iter <= 32
-    uint32_t cur = plan.lut[k];
 #pragma unroll 1
-    for (; k < n_iter && k < kMad24From; ++k) {                   // the first rotations: ROM words of 24 bits and more
-        const uint32_t nxt = plan.lut[k + 1];
-        rot_step_dyn(x, y, z, k, cur, false);
-        cur = nxt;
-    }
+    for (; k < n_iter && k < kMad24From; ++k)                     // the first rotations: ROM words of 24 bits and more
+        rot_step_dyn(x, y, z, k, (uint32_t)__builtin_amdgcn_readlane((int)lutv, k), false);
 #pragma unroll 1
-    for (; k < n_iter; ++k) {
-        const uint32_t nxt = plan.lut[k + 1];
-        rot_step_dyn(x, y, z, k, cur, true);
-        cur = nxt;
-    }
+    for (; k < n_iter; ++k)
+        rot_step_dyn(x, y, z, k, (uint32_t)__builtin_amdgcn_readlane((int)lutv, k), true);
 }
 
 template <int NTERMS, int MODE>
@@ -1010,6 +1006,7 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwCordicCfg cfg, Bh
     // ---- phase 2: one lane per r ----
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t r = wg_r0 + threadIdx.x;
+    const uint32_t lutv = plan.lut[threadIdx.x & 31u];                    // lane k (and k + 32) holds lut[k]
     acc_t acc[2][4];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -1024,7 +1021,7 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwCordicCfg cfg, Bh
         const int k0 = __builtin_amdgcn_readfirstlane(gk[i]);
         const uint32_t t = (K * r + hodd * H) & emask;
         int32_t z = (int32_t)(((t >> plan.z_shr) << plan.z_shl) + gdz[i]);
-        chain_from(x, y, z, k0, n_iter, plan);
+        chain_from(x, y, z, k0, n_iter, lutv);
         return make_int2((int32_t)(x >> plan.out_shr), (int32_t)(y >> plan.out_shr));
     };
 #define BHW_FD_HARMONIC(K)                                                                           \
@@ -1076,7 +1073,13 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwCordicCfg cfg, Bh
 // W < PW <= 30 anyway; the launcher checks).
 // ---------------------------------------------------------------------------------------
 constexpr int kRlRun = 16;
-constexpr int kRlBlock = 128;
+#ifndef BHW_RL_BLOCK
+#define BHW_RL_BLOCK 128
+#endif
+#ifndef BHW_RL_DIRECT_STORE
+#define BHW_RL_DIRECT_STORE 0      // 1: every lane stores its own 16-byte granules (64-byte stride across lanes), no LDS tile
+#endif
+constexpr int kRlBlock = BHW_RL_BLOCK;
 
 // LDS tile of one (wave, image): 1024 values as 256 granules of 16 bytes, granule index XOR-swizzled inside rows of eight
 // so that both the producer pattern (granule 4*lane + c) and the consumer pattern (granule 64*s + lane) are conflict-free.
@@ -1086,7 +1089,9 @@ template <int NTERMS, int MODE>
 __global__ __launch_bounds__(kRlBlock) void k_runlength_window(BhwCordicCfg cfg, BhwWinCfg win, const int2 *__restrict__ table,
                                                               int32_t *__restrict__ out)
 {
+#if !BHW_RL_DIRECT_STORE
     __shared__ int4 tile[kRlBlock / 64][4][256];                          // [wave][image j][granule]: 16 KiB per wave
+#endif
     const uint32_t lq = cfg.phi_width - 2;
     const uint32_t E = 1u << lq, emask = E - 1u, H = E >> 1;
     const uint32_t W = cfg.dat_width, zs = cfg.z_shr, zmask = (1u << zs) - 1u;
@@ -1150,6 +1155,12 @@ __global__ __launch_bounds__(kRlBlock) void k_runlength_window(BhwCordicCfg cfg,
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j][e] = finish(acc[j]);
             }
+#if BHW_RL_DIRECT_STORE
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<int4 *>(out + (uint64_t)(r0 + 4u * (uint32_t)c4 + h * H) + (uint64_t)j * E) = make_int4(v[j][0], v[j][1], v[j][2], v[j][3]);
+        }
+#else
             const uint32_t g = rl_swizzle(4u * lane + (uint32_t)c4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) tile[wave][j][g] = make_int4(v[j][0], v[j][1], v[j][2], v[j][3]);
@@ -1165,6 +1176,7 @@ __global__ __launch_bounds__(kRlBlock) void k_runlength_window(BhwCordicCfg cfg,
                 *reinterpret_cast<int4 *>(out + idx) = d;
             }
         __syncthreads();
+#endif
     }
 }
 
