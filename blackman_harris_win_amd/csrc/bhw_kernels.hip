@@ -904,7 +904,7 @@ struct BhwFoldPlan {
     uint32_t lut[34];                        // rescaled ROM as 32-bit words (quarter circle <= 2^32); [32], [33] = 0: the loop reads one ahead
     int64_t  x0;
     uint32_t n_iter, z_shr, z_shl, out_shr;
-    uint32_t n_runs, pad;
+    uint32_t n_runs, phi_width, dat_width, ones_neg;
     uint32_t r0[kFoldRunsMax];               // first ring index of each run
     uint32_t r_end[kFoldRunsMax];            // one past its last
     uint32_t wg_first[kFoldRunsMax + 1];     // first workgroup of each run; [n_runs] = grid size
@@ -948,8 +948,11 @@ __device__ __forceinline__ void chain_from(int64_t &x, int64_t &y, int32_t &z, i
         rot_step_dyn(x, y, z, k, (uint32_t)__builtin_amdgcn_readlane((int)lutv, k), true);
 }
 
+#ifndef BHW_FD_STAGE
+#define BHW_FD_STAGE 1      // 1: copy the kernel arguments into LDS with one coalesced vector load first (see below)
+#endif
 template <int NTERMS, int MODE>
-__global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwCordicCfg cfg, BhwWinCfg win, BhwFoldPlan plan, int32_t *__restrict__ out)
+__global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win_arg, BhwFoldPlan plan_arg, int32_t *__restrict__ out)
 {
     using acc_t = typename std::conditional<MODE == 2, Sum32, int32_t>::type;
     constexpr int NCH = fold_chains(NTERMS);
@@ -957,16 +960,43 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwCordicCfg cfg, Bh
     __shared__ int64_t gx[kWavesMax * NCH], gy[kWavesMax * NCH];
     __shared__ uint32_t gdz[kWavesMax * NCH];
     __shared__ int32_t gk[kWavesMax * NCH];
+#if BHW_FD_STAGE
+    // The kernel arguments live in host-visible memory: every 64-byte line of them costs a round trip the first time a CU
+    // touches it, and scalar loads scattered through the kernel (ROM words per rotation, a weight per harmonic, run bounds)
+    // pay those round trips one after the other -- microseconds on a launch of a few waves.  One coalesced vector load of
+    // the whole block into LDS up front pays them together; everything below reads LDS.
+    __shared__ BhwFoldPlan plan_s;
+    __shared__ BhwWinCfg win_s;
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(&plan_arg);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&plan_s);
+        for (uint32_t i = threadIdx.x; i < sizeof(BhwFoldPlan) / 4u; i += blockDim.x) dst[i] = src[i];
+        src = reinterpret_cast<const uint32_t *>(&win_arg);
+        dst = reinterpret_cast<uint32_t *>(&win_s);
+        for (uint32_t i = threadIdx.x; i < sizeof(BhwWinCfg) / 4u; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const BhwFoldPlan &plan = plan_s;
+    const BhwWinCfg &win = win_s;
+#else
+    const BhwFoldPlan &plan = plan_arg;
+    const BhwWinCfg &win = win_arg;
+#endif
+    BhwCordicCfg cfg;                                                     // tile_harmonic() reads ones_neg only
+    cfg.ones_neg = plan.ones_neg;
 
-    const uint32_t lq = cfg.phi_width - 2;
+    const uint32_t lq = plan.phi_width - 2;
     const uint32_t E = 1u << lq, emask = E - 1u, H = E >> 1;
-    const uint32_t W = cfg.dat_width;
-    const int n_iter = (int)plan.n_iter;
+    const uint32_t W = plan.dat_width;
+    const int n_iter = (int)__builtin_amdgcn_readfirstlane(plan.n_iter);
     uint32_t run = 0;                                                     // scalar search: at most kFoldRunsMax runs
-    while (run + 1u < plan.n_runs && blockIdx.x >= plan.wg_first[run + 1u]) ++run;
-    const uint32_t wg_r0 = plan.r0[run] + (blockIdx.x - plan.wg_first[run]) * blockDim.x;
-    const uint32_t r_end = plan.r_end[run];
+    const uint32_t n_runs = __builtin_amdgcn_readfirstlane(plan.n_runs);
+    while (run + 1u < n_runs && blockIdx.x >= (uint32_t)__builtin_amdgcn_readfirstlane(plan.wg_first[run + 1u])) ++run;
+    const uint32_t wg_r0 = __builtin_amdgcn_readfirstlane(plan.r0[run] + (blockIdx.x - plan.wg_first[run]) * blockDim.x);
+    const uint32_t r_end = __builtin_amdgcn_readfirstlane(plan.r_end[run]);
     const uint32_t n_waves = blockDim.x >> 6;
+    const uint32_t z_shr = __builtin_amdgcn_readfirstlane(plan.z_shr), z_shl = __builtin_amdgcn_readfirstlane(plan.z_shl);
+    const uint32_t out_shr = __builtin_amdgcn_readfirstlane(plan.out_shr);
 
     // ---- phase 1: shared rotation prefix of every (wave, chain) ----
     // chain slot c -> harmonic K and half-period image: (1,0) (1,1) (2) (3,0) (3,1) (4) (5,0) (5,1) (6)
@@ -977,10 +1007,13 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwCordicCfg cfg, Bh
         const uint32_t rf = wg_r0 + (wv << 6);
         const uint32_t t0 = (K * rf + hodd * H) & emask;
         const uint32_t tl = t0 + 63u * K;                                 // last leaf, if the 64 leaves do not wrap past E
-        const uint32_t z0f = (t0 >> plan.z_shr) << plan.z_shl;
+        const uint32_t z0f = (t0 >> z_shr) << z_shl;
         bool live = tl <= emask;                                          // wrapped groups are not contiguous in angle: no sharing
-        const uint32_t span = live ? ((tl >> plan.z_shr) << plan.z_shl) - z0f : 0u;
+        const uint32_t span = live ? ((tl >> z_shr) << z_shl) - z0f : 0u;
         int64_t x = plan.x0, y = plan.x0;                                 // after rotation 0 (z0 >= 0 always adds)
+#ifdef BHW_FD_NO_PREFIX
+        live = false;
+#endif
         int32_t zf = (int32_t)(z0f - plan.lut[0]);
         int k = 1;
         constexpr int kmax = kPrefixMax < 32 ? kPrefixMax : 32;
@@ -1020,9 +1053,9 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwCordicCfg cfg, Bh
         int64_t x = gx[i], y = gy[i];
         const int k0 = __builtin_amdgcn_readfirstlane(gk[i]);
         const uint32_t t = (K * r + hodd * H) & emask;
-        int32_t z = (int32_t)(((t >> plan.z_shr) << plan.z_shl) + gdz[i]);
+        int32_t z = (int32_t)(((t >> z_shr) << z_shl) + gdz[i]);
         chain_from(x, y, z, k0, n_iter, lutv);
-        return make_int2((int32_t)(x >> plan.out_shr), (int32_t)(y >> plan.out_shr));
+        return make_int2((int32_t)(x >> out_shr), (int32_t)(y >> out_shr));
     };
 #define BHW_FD_HARMONIC(K)                                                                           \
     if constexpr (NTERMS > K) {                                                                      \
@@ -1881,6 +1914,9 @@ int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg 
     plan.z_shl = c.z_shl;
     plan.out_shr = c.out_shr;
     plan.n_runs = n_runs;
+    plan.phi_width = c.phi_width;
+    plan.dat_width = c.dat_width;
+    plan.ones_neg = c.ones_neg;
     uint64_t total = 0;
     for (uint32_t i = 0; i < n_runs; ++i) total += runs[i].r_end - runs[i].r0;
     // short launches: one wave per workgroup spreads the few waves over more CUs
@@ -1898,9 +1934,9 @@ int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg 
     const dim3 grid(wg), blk(block);
 #define BHW_FD_NT(NT)                                                                                       \
     do {                                                                                                    \
-        if (mode == 0)      BHW_LAUNCH((k_fold_direct<NT, 0>), grid, blk, 0, st, c, w, plan, d_out);        \
-        else if (mode == 1) BHW_LAUNCH((k_fold_direct<NT, 1>), grid, blk, 0, st, c, w, plan, d_out);        \
-        else                BHW_LAUNCH((k_fold_direct<NT, 2>), grid, blk, 0, st, c, w, plan, d_out);        \
+        if (mode == 0)      BHW_LAUNCH((k_fold_direct<NT, 0>), grid, blk, 0, st, w, plan, d_out);           \
+        else if (mode == 1) BHW_LAUNCH((k_fold_direct<NT, 1>), grid, blk, 0, st, w, plan, d_out);           \
+        else                BHW_LAUNCH((k_fold_direct<NT, 2>), grid, blk, 0, st, w, plan, d_out);           \
     } while (0)
     switch (w.n_terms) {
     case 2: BHW_FD_NT(2); break;
