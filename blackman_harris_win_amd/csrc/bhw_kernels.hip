@@ -948,55 +948,38 @@ __device__ __forceinline__ void chain_from(int64_t &x, int64_t &y, int32_t &z, i
         rot_step_dyn(x, y, z, k, (uint32_t)__builtin_amdgcn_readlane((int)lutv, k), true);
 }
 
-#ifndef BHW_FD_STAGE
-#define BHW_FD_STAGE 1      // 1: copy the kernel arguments into LDS with one coalesced vector load first (see below)
-#endif
-template <int NTERMS, int MODE>
-__global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win_arg, BhwFoldPlan plan_arg, int32_t *__restrict__ out)
+// LOCKSTEP selects how phase 2 walks a lane's chains:
+//   false: one chain after the other, each from its own split rotation (fewest rotations: the form for launches that fill the
+//          chip, which are bound by vector issue);
+//   true : all chains of the lane in one loop from the earliest split rotation of the wave -- a few rotations are repeated, but
+//          the NCH independent rotations per iteration hide the ~15-cycle dependent-issue latency that a single chain exposes
+//          when a launch has only a wave or two per SIMD (a 2^16-point window: 13 -> 6 us).
+// Phase 1 parks the shared state after every prefix rotation (20 levels x tasks x 20 bytes of LDS), so either form picks its
+// start level.
+constexpr int kFoldLevels = (kPrefixMax < 32 ? kPrefixMax : 32) + 1;
+
+template <int NTERMS, int MODE, bool LOCKSTEP>
+__global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win, BhwFoldPlan plan, int32_t *__restrict__ out)
 {
     using acc_t = typename std::conditional<MODE == 2, Sum32, int32_t>::type;
     constexpr int NCH = fold_chains(NTERMS);
-    constexpr int kWavesMax = kFoldBlock / 64;
-    __shared__ int64_t gx[kWavesMax * NCH], gy[kWavesMax * NCH];
-    __shared__ uint32_t gdz[kWavesMax * NCH];
-    __shared__ int32_t gk[kWavesMax * NCH];
-#if BHW_FD_STAGE
-    // The kernel arguments live in host-visible memory: every 64-byte line of them costs a round trip the first time a CU
-    // touches it, and scalar loads scattered through the kernel (ROM words per rotation, a weight per harmonic, run bounds)
-    // pay those round trips one after the other -- microseconds on a launch of a few waves.  One coalesced vector load of
-    // the whole block into LDS up front pays them together; everything below reads LDS.
-    __shared__ BhwFoldPlan plan_s;
-    __shared__ BhwWinCfg win_s;
-    {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(&plan_arg);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(&plan_s);
-        for (uint32_t i = threadIdx.x; i < sizeof(BhwFoldPlan) / 4u; i += blockDim.x) dst[i] = src[i];
-        src = reinterpret_cast<const uint32_t *>(&win_arg);
-        dst = reinterpret_cast<uint32_t *>(&win_s);
-        for (uint32_t i = threadIdx.x; i < sizeof(BhwWinCfg) / 4u; i += blockDim.x) dst[i] = src[i];
-    }
-    __syncthreads();
-    const BhwFoldPlan &plan = plan_s;
-    const BhwWinCfg &win = win_s;
-#else
-    const BhwFoldPlan &plan = plan_arg;
-    const BhwWinCfg &win = win_arg;
-#endif
+    constexpr int kTasks = (kFoldBlock / 64) * NCH;
+    __shared__ int64_t gx[kFoldLevels][kTasks], gy[kFoldLevels][kTasks];   // [level = rotations applied][wave * NCH + chain]
+    __shared__ uint32_t gdz[kFoldLevels][kTasks];
+    __shared__ int32_t gk[kTasks];
     BhwCordicCfg cfg;                                                     // tile_harmonic() reads ones_neg only
     cfg.ones_neg = plan.ones_neg;
 
     const uint32_t lq = plan.phi_width - 2;
     const uint32_t E = 1u << lq, emask = E - 1u, H = E >> 1;
     const uint32_t W = plan.dat_width;
-    const int n_iter = (int)__builtin_amdgcn_readfirstlane(plan.n_iter);
+    const int n_iter = (int)plan.n_iter;
     uint32_t run = 0;                                                     // scalar search: at most kFoldRunsMax runs
-    const uint32_t n_runs = __builtin_amdgcn_readfirstlane(plan.n_runs);
-    while (run + 1u < n_runs && blockIdx.x >= (uint32_t)__builtin_amdgcn_readfirstlane(plan.wg_first[run + 1u])) ++run;
-    const uint32_t wg_r0 = __builtin_amdgcn_readfirstlane(plan.r0[run] + (blockIdx.x - plan.wg_first[run]) * blockDim.x);
-    const uint32_t r_end = __builtin_amdgcn_readfirstlane(plan.r_end[run]);
+    while (run + 1u < plan.n_runs && blockIdx.x >= plan.wg_first[run + 1u]) ++run;
+    const uint32_t wg_r0 = plan.r0[run] + (blockIdx.x - plan.wg_first[run]) * blockDim.x;
+    const uint32_t r_end = plan.r_end[run];
     const uint32_t n_waves = blockDim.x >> 6;
-    const uint32_t z_shr = __builtin_amdgcn_readfirstlane(plan.z_shr), z_shl = __builtin_amdgcn_readfirstlane(plan.z_shl);
-    const uint32_t out_shr = __builtin_amdgcn_readfirstlane(plan.out_shr);
+    const uint32_t z_shr = plan.z_shr, z_shl = plan.z_shl, out_shr = plan.out_shr;
 
     // ---- phase 1: shared rotation prefix of every (wave, chain) ----
     // chain slot c -> harmonic K and half-period image: (1,0) (1,1) (2) (3,0) (3,1) (4) (5,0) (5,1) (6)
@@ -1011,14 +994,13 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win_arg, B
         bool live = tl <= emask;                                          // wrapped groups are not contiguous in angle: no sharing
         const uint32_t span = live ? ((tl >> z_shr) << z_shl) - z0f : 0u;
         int64_t x = plan.x0, y = plan.x0;                                 // after rotation 0 (z0 >= 0 always adds)
-#ifdef BHW_FD_NO_PREFIX
-        live = false;
-#endif
         int32_t zf = (int32_t)(z0f - plan.lut[0]);
         int k = 1;
-        constexpr int kmax = kPrefixMax < 32 ? kPrefixMax : 32;
+        gx[1][threadIdx.x] = x;
+        gy[1][threadIdx.x] = y;
+        gdz[1][threadIdx.x] = (uint32_t)zf - z0f;                         // z_level(leaf) = z0(leaf) + this, for every leaf of the group
 #pragma unroll
-        for (int kk = 1; kk < kmax; ++kk) {
+        for (int kk = 1; kk < kFoldLevels - 1; ++kk) {
             if (live && kk < n_iter) {
                 const int32_t zl = (int32_t)((uint32_t)zf + span);
                 if ((zf < 0) != (zl < 0)) {
@@ -1026,12 +1008,12 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win_arg, B
                 } else {
                     rot_step(x, y, zf, kk, plan.lut[kk]);
                     k = kk + 1;
+                    gx[kk + 1][threadIdx.x] = x;
+                    gy[kk + 1][threadIdx.x] = y;
+                    gdz[kk + 1][threadIdx.x] = (uint32_t)zf - z0f;
                 }
             }
         }
-        gx[threadIdx.x] = x;
-        gy[threadIdx.x] = y;
-        gdz[threadIdx.x] = (uint32_t)zf - z0f;                            // z_k(leaf) = z0(leaf) + this, for every leaf of the group
         gk[threadIdx.x] = k;
     }
     __syncthreads();
@@ -1048,12 +1030,50 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win_arg, B
             if constexpr (MODE == 2) acc[h][j] = Sum32{win.aa[0] >> 2, win.aa[0] & 3};
             else acc[h][j] = win.aa[0];
         }
+    // slot -> (K, half-period image) as compile-time functions of the slot
+    auto slot_K = [](int slot) { return 2 * (slot / 3) + 1 + (slot % 3 == 2 ? 1 : 0); };
+    auto slot_h = [](int slot) { return slot % 3 == 1 ? 1u : 0u; };
+    int2 cs[NCH];
+    if constexpr (LOCKSTEP) {
+        int kc = 32;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int kq = __builtin_amdgcn_readfirstlane(gk[wave * NCH + c]);
+            kc = kq < kc ? kq : kc;
+        }
+        int64_t x[NCH], y[NCH];
+        int32_t z[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const uint32_t i = wave * NCH + c;
+            x[c] = gx[kc][i];
+            y[c] = gy[kc][i];
+            const uint32_t t = ((uint32_t)slot_K(c) * r + slot_h(c) * H) & emask;
+            z[c] = (int32_t)(((t >> z_shr) << z_shl) + gdz[kc][i]);
+        }
+        int k = kc;
+#pragma unroll 1
+        for (; k < n_iter && k < kMad24From; ++k) {
+            const uint32_t lutk = (uint32_t)__builtin_amdgcn_readlane((int)lutv, k);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) rot_step_dyn(x[c], y[c], z[c], k, lutk, false);
+        }
+#pragma unroll 1
+        for (; k < n_iter; ++k) {
+            const uint32_t lutk = (uint32_t)__builtin_amdgcn_readlane((int)lutv, k);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) rot_step_dyn(x[c], y[c], z[c], k, lutk, true);
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) cs[c] = make_int2((int32_t)(x[c] >> out_shr), (int32_t)(y[c] >> out_shr));
+    }
     auto chain = [&](const uint32_t slot, const uint32_t K, const uint32_t hodd) -> int2 {
+        if constexpr (LOCKSTEP) return cs[slot];
         const uint32_t i = wave * NCH + slot;                             // scalar: the parked state is read as a broadcast
-        int64_t x = gx[i], y = gy[i];
         const int k0 = __builtin_amdgcn_readfirstlane(gk[i]);
+        int64_t x = gx[k0][i], y = gy[k0][i];
         const uint32_t t = (K * r + hodd * H) & emask;
-        int32_t z = (int32_t)(((t >> z_shr) << z_shl) + gdz[i]);
+        int32_t z = (int32_t)(((t >> z_shr) << z_shl) + gdz[k0][i]);
         chain_from(x, y, z, k0, n_iter, lutv);
         return make_int2((int32_t)(x >> out_shr), (int32_t)(y >> out_shr));
     };
@@ -1932,11 +1952,21 @@ int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg 
     if (!wg) return 0;
     const int mode = (w.combine != BHW_COMBINE_HLS) ? 2 : (c.ones_neg ? 1 : 0);
     const dim3 grid(wg), blk(block);
+    // fewer than ~4 waves per SIMD in the whole launch: latency-bound, walk the chains in lockstep
+#ifndef BHW_FD_LOCKSTEP_MAX
+#define BHW_FD_LOCKSTEP_MAX (1u << 18)
+#endif
+    const bool lockstep = total <= BHW_FD_LOCKSTEP_MAX;
+#define BHW_FD_NT_M(NT, M)                                                                                  \
+    do {                                                                                                    \
+        if (lockstep) BHW_LAUNCH((k_fold_direct<NT, M, true>), grid, blk, 0, st, w, plan, d_out);           \
+        else          BHW_LAUNCH((k_fold_direct<NT, M, false>), grid, blk, 0, st, w, plan, d_out);          \
+    } while (0)
 #define BHW_FD_NT(NT)                                                                                       \
     do {                                                                                                    \
-        if (mode == 0)      BHW_LAUNCH((k_fold_direct<NT, 0>), grid, blk, 0, st, w, plan, d_out);           \
-        else if (mode == 1) BHW_LAUNCH((k_fold_direct<NT, 1>), grid, blk, 0, st, w, plan, d_out);           \
-        else                BHW_LAUNCH((k_fold_direct<NT, 2>), grid, blk, 0, st, w, plan, d_out);           \
+        if (mode == 0)      BHW_FD_NT_M(NT, 0);                                                             \
+        else if (mode == 1) BHW_FD_NT_M(NT, 1);                                                             \
+        else                BHW_FD_NT_M(NT, 2);                                                             \
     } while (0)
     switch (w.n_terms) {
     case 2: BHW_FD_NT(2); break;
@@ -1947,6 +1977,7 @@ int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg 
     default: return (int)hipErrorInvalidValue;
     }
 #undef BHW_FD_NT
+#undef BHW_FD_NT_M
     return finish(hipSuccess);
 }
 

@@ -9,16 +9,21 @@ import statistics
 import subprocess
 import sys
 
-import torch
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from blackman_harris_win_amd import _build, binding  # noqa: E402
 
 
 def build_variant(idx, flags):
-    out = os.path.join(ROOT, "gpurun_out", f"libbhw_ab{idx}.so")
+    # variants are cached under build/ab/ by (flags, source hash): prebuild them in the CPU container with --build-only,
+    # the snapshot carries them to the GPU box (GPU minutes are not spent compiling)
+    import hashlib
+    srcs = [os.path.join(_build.CSRC, f) for f in ("bhw_api.cpp", "bhw_kernels.hip", "bhw_rom.c", "bhw_internal.h", "bhw_tables.inc")]
+    tag = hashlib.sha256((flags + _build._digest(srcs)).encode()).hexdigest()[:16]
+    out = os.path.join(ROOT, "build", "ab", f"libbhw_{tag}.so")
     os.makedirs(os.path.dirname(out), exist_ok=True)
+    if os.path.exists(out):
+        return out
     csrc = _build.CSRC
     rom_o = os.path.join(csrc, "bhw_rom.o")
     if not os.path.exists(rom_o):
@@ -32,12 +37,17 @@ def build_variant(idx, flags):
 
 
 def main():
-    variants = sys.argv[1:]
+    variants = [a for a in sys.argv[1:] if a != "--build-only"]
+    if "--build-only" in sys.argv:
+        for i, f in enumerate(variants):
+            print(build_variant(i, f))
+        return
     pw = int(os.environ.get("AB_PW", "26"))
     win = int(os.environ.get("AB_WIN", "7"))
     width = int(os.environ.get("AB_W", "32"))
     rounds = int(os.environ.get("AB_ROUNDS", "8"))
     inner = int(os.environ.get("AB_INNER", "100"))
+    import torch
     torch.zeros(1, device="cuda")
     libs = []
     for i, f in enumerate(variants):
