@@ -317,12 +317,11 @@ bool has_whole_period(const bhw_params *p, uint64_t n0, uint64_t count)
     return count >= (N - n0 % N) % N + N;
 }
 
-// Whole periods up to this length go through the fused kernel under AUTO: one launch of 9/8 chains per coefficient beats two
-// dependent launches around a table of 1/4 chain per coefficient while the call is launch- and latency-bound
-// (measured: profiles/r02_small_windows.json).
-#ifndef BHW_FUSED_MAX_PW
-#define BHW_FUSED_MAX_PW 20
-#endif
+// Whole periods up to this length go through the fused kernel under AUTO: one launch of 5/8 .. 9/8 chains per coefficient beats
+// two dependent launches around a table of 1/4 chain per coefficient while the call is launch- and latency-bound.  Measured per
+// call (profiles/r02_small_windows.json): BH-4/24-bit fused 8.0 / 12.1 / 17.0 us at 2^20 / 2^21 / 2^22 against 11.7 / 14.6 /
+// 19.9 us for the table strategy; BH-7/32-bit 9.0 (2^16) / 13.3 / 21.8 / 33.5 us against 11.9 / 11.9 / 16.8 / 27.5 us.
+uint32_t fused_max_pw(uint32_t n_terms) { return n_terms <= 5 ? 22u : 19u; }
 
 // AUTO: the fused kernel for short whole periods; else build the shared table when it replaces clearly more CORDIC chains
 // than it costs; else one chain per harmonic per coefficient.
@@ -332,7 +331,7 @@ uint32_t pick_algo(const bhw_params *p, const BhwCordicCfg &c, uint64_t n0, uint
     const bool fused_ok = bhwk_fold_direct_applicable(c) && has_whole_period(p, n0, count);
     if (requested == BHW_ALGO_FUSED) return fused_ok ? BHW_ALGO_FUSED : BHW_ALGO_TABLE;
     if (requested == BHW_ALGO_DIRECT || requested == BHW_ALGO_TABLE) return requested;
-    if (fused_ok && p->phi_width <= BHW_FUSED_MAX_PW) return BHW_ALGO_FUSED;
+    if (fused_ok && p->phi_width <= fused_max_pw(p->n_terms)) return BHW_ALGO_FUSED;
     const uint64_t chains_direct = count * (p->n_terms - 1);
     return chains_direct >= 2 * table_entries(c) ? BHW_ALGO_TABLE : BHW_ALGO_DIRECT;
 }

@@ -1127,7 +1127,7 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win, BhwFo
 // ---------------------------------------------------------------------------------------
 constexpr int kRlRun = 16;
 #ifndef BHW_RL_BLOCK
-#define BHW_RL_BLOCK 128
+#define BHW_RL_BLOCK 64
 #endif
 #ifndef BHW_RL_DIRECT_STORE
 #define BHW_RL_DIRECT_STORE 0      // 1: every lane stores its own 16-byte granules (64-byte stride across lanes), no LDS tile
@@ -1137,13 +1137,16 @@ constexpr int kRlBlock = BHW_RL_BLOCK;
 // LDS tile of one (wave, image): 1024 values as 256 granules of 16 bytes, granule index XOR-swizzled inside rows of eight
 // so that both the producer pattern (granule 4*lane + c) and the consumer pattern (granule 64*s + lane) are conflict-free.
 __device__ __forceinline__ uint32_t rl_swizzle(uint32_t g) { return (g & ~7u) | ((g ^ (g >> 3)) & 7u); }
+// the same for 8-byte granules (rows of sixteen): dat_width <= 16 keeps the tile as int16, half the LDS, twice the waves per CU
+__device__ __forceinline__ uint32_t rl_swizzle16(uint32_t g) { return (g & ~15u) | ((g ^ (g >> 4)) & 15u); }
 
-template <int NTERMS, int MODE>
+template <int NTERMS, int MODE, bool NARROW>
 __global__ __launch_bounds__(kRlBlock) void k_runlength_window(BhwCordicCfg cfg, BhwWinCfg win, const int2 *__restrict__ table,
                                                               int32_t *__restrict__ out)
 {
 #if !BHW_RL_DIRECT_STORE
-    __shared__ int4 tile[kRlBlock / 64][4][256];                          // [wave][image j][granule]: 16 KiB per wave
+    using gran_t = typename std::conditional<NARROW, uint2, int4>::type;  // four coefficients: 4 x int16 or 4 x int32
+    __shared__ gran_t tile[kRlBlock / 64][4][256];                        // [wave][image j][granule]: 8 / 16 KiB per wave
 #endif
     const uint32_t lq = cfg.phi_width - 2;
     const uint32_t E = 1u << lq, emask = E - 1u, H = E >> 1;
@@ -1214,9 +1217,17 @@ __global__ __launch_bounds__(kRlBlock) void k_runlength_window(BhwCordicCfg cfg,
                 *reinterpret_cast<int4 *>(out + (uint64_t)(r0 + 4u * (uint32_t)c4 + h * H) + (uint64_t)j * E) = make_int4(v[j][0], v[j][1], v[j][2], v[j][3]);
         }
 #else
-            const uint32_t g = rl_swizzle(4u * lane + (uint32_t)c4);
+            if constexpr (NARROW) {
+                const uint32_t g = rl_swizzle16(4u * lane + (uint32_t)c4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) tile[wave][j][g] = make_int4(v[j][0], v[j][1], v[j][2], v[j][3]);
+                for (int j = 0; j < 4; ++j)
+                    tile[wave][j][g] = make_uint2(((uint32_t)v[j][0] & 0xFFFFu) | ((uint32_t)v[j][1] << 16),
+                                                  ((uint32_t)v[j][2] & 0xFFFFu) | ((uint32_t)v[j][3] << 16));
+            } else {
+                const uint32_t g = rl_swizzle(4u * lane + (uint32_t)c4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tile[wave][j][g] = make_int4(v[j][0], v[j][1], v[j][2], v[j][3]);
+            }
         }
         __syncthreads();
         // store instruction s of image j: lane l writes ring lanes r_wave + 256 s + 4 l .. + 3 (1 KiB per wave instruction)
@@ -1224,7 +1235,13 @@ __global__ __launch_bounds__(kRlBlock) void k_runlength_window(BhwCordicCfg cfg,
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int sgrp = 0; sgrp < 4; ++sgrp) {
-                const int4 d = tile[wave][j][rl_swizzle(64u * (uint32_t)sgrp + lane)];
+                int4 d;
+                if constexpr (NARROW) {
+                    const uint2 q = tile[wave][j][rl_swizzle16(64u * (uint32_t)sgrp + lane)];
+                    d = make_int4((int32_t)(int16_t)(q.x & 0xFFFFu), (int32_t)q.x >> 16, (int32_t)(int16_t)(q.y & 0xFFFFu), (int32_t)q.y >> 16);
+                } else {
+                    d = tile[wave][j][rl_swizzle(64u * (uint32_t)sgrp + lane)];
+                }
                 const uint64_t idx = (uint64_t)(r_wave + 256u * (uint32_t)sgrp + 4u * lane + h * H) + (uint64_t)j * E;
                 *reinterpret_cast<int4 *>(out + idx) = d;
             }
@@ -2001,11 +2018,20 @@ int bhwk_runlength_window(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWi
     const uint32_t H = 1u << (c.phi_width - 3);
     const dim3 grid(H / (kRlBlock * kRlRun)), block(kRlBlock);
     const int mode = (w.combine != BHW_COMBINE_HLS) ? 2 : (c.ones_neg ? 1 : 0);
+#ifndef BHW_RL_NARROW_MAX
+#define BHW_RL_NARROW_MAX 16
+#endif
+    const bool narrow = c.dat_width <= BHW_RL_NARROW_MAX;                       // coefficients fit int16: half-size LDS tile
+#define BHW_RL_NT_M(NT, M)                                                                                                     \
+    do {                                                                                                                       \
+        if (narrow) BHW_LAUNCH((k_runlength_window<NT, M, true>), grid, block, 0, st, c, w, (const int2 *)d_table, d_out);     \
+        else        BHW_LAUNCH((k_runlength_window<NT, M, false>), grid, block, 0, st, c, w, (const int2 *)d_table, d_out);    \
+    } while (0)
 #define BHW_RL_NT(NT)                                                                                                          \
     do {                                                                                                                       \
-        if (mode == 0)      BHW_LAUNCH((k_runlength_window<NT, 0>), grid, block, 0, st, c, w, (const int2 *)d_table, d_out);   \
-        else if (mode == 1) BHW_LAUNCH((k_runlength_window<NT, 1>), grid, block, 0, st, c, w, (const int2 *)d_table, d_out);   \
-        else                BHW_LAUNCH((k_runlength_window<NT, 2>), grid, block, 0, st, c, w, (const int2 *)d_table, d_out);   \
+        if (mode == 0)      BHW_RL_NT_M(NT, 0);                                                                                \
+        else if (mode == 1) BHW_RL_NT_M(NT, 1);                                                                                \
+        else                BHW_RL_NT_M(NT, 2);                                                                                \
     } while (0)
     switch (w.n_terms) {
     case 2: BHW_RL_NT(2); break;
@@ -2016,6 +2042,7 @@ int bhwk_runlength_window(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWi
     default: return (int)hipErrorInvalidValue;
     }
 #undef BHW_RL_NT
+#undef BHW_RL_NT_M
     return finish(hipSuccess);
 }
 
