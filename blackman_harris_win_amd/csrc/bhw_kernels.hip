@@ -116,20 +116,29 @@ __device__ __forceinline__ bool fits_bits(int32_t v, uint32_t bits)
     return (uint32_t)(v + (1 << (bits - 1))) < (1u << bits);
 }
 
+// Table reads address as (scalar base) + (32-bit byte offset per lane): the tables are below 4 GiB, and with the offset held
+// in 32 bits the compiler emits the saddr form  global_load v, v_off, s[base:base+1]  instead of a 64-bit add per address
+// (the tile kernel issues 54 such loads per thread).
+template <typename T>
+__device__ __forceinline__ T ld_off(const void *__restrict__ base, uint32_t byte_off)
+{
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
 // FMT: -1 format read from cfg.tab_dlog at run time, 0 plain int2 entries, 1 delta16, 2 residual.
 template <int KCLASS = 0, int FMT = -1, int SPLIT = -1>
 __device__ __forceinline__ int2 tab_load(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t log2_entries)
 {
     const uint32_t idx = tab_index<KCLASS, SPLIT>(u, log2_entries, cfg.tab_split);
-    if (FMT == 0 || (FMT < 0 && cfg.tab_dlog == 0)) return reinterpret_cast<const int2 *>(table)[idx];
+    if (FMT == 0 || (FMT < 0 && cfg.tab_dlog == 0)) return ld_off<int2>(table, idx << 3);
     if (FMT == 1 || (FMT < 0 && cfg.tab_dlog == kPackLog)) {
-        const uint32_t e = reinterpret_cast<const uint32_t *>(table)[idx];
-        const int2 base = reinterpret_cast<const int2 *>(cfg.tab_coarse)[u >> kPackLog];
+        const uint32_t e = ld_off<uint32_t>(table, idx << 2);
+        const int2 base = ld_off<int2>(cfg.tab_coarse, (u >> kPackLog) << 3);
         return make_int2(base.x + (int32_t)(int16_t)(e & 0xFFFFu), base.y + ((int32_t)e >> 16));
     }
     const uint32_t d = cfg.tab_dlog;
-    const uint32_t e = reinterpret_cast<const uint16_t *>(table)[idx];
-    const int2 p = tab_predict(reinterpret_cast<const int4 *>(cfg.tab_coarse)[u >> d], u & ((1u << d) - 1u), d);
+    const uint32_t e = ld_off<uint16_t>(table, idx << 1);
+    const int2 p = tab_predict(ld_off<int4>(cfg.tab_coarse, (u >> d) << 4), u & ((1u << d) - 1u), d);
     return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
 }
 
@@ -639,6 +648,9 @@ struct Sum32 {
     __device__ __forceinline__ Sum32 &operator+=(const Sum32 &o) { hi += o.hi; lo += o.lo; return *this; }
 };
 
+__device__ __forceinline__ int32_t acc_value(int32_t v) { return v; }
+__device__ __forceinline__ int32_t acc_value(const Sum32 &v) { return v.hi; }
+
 template <uint32_t COMBINE>
 __device__ __forceinline__ void w32_term(Sum32 &acc, int32_t a, int32_t v, uint32_t k, uint32_t W)
 {
@@ -853,12 +865,27 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
         else return (int32_t)((uint32_t)acc[b][h][j] << (32u - W)) >> (32u - W);   // (win_t)(...) wrap to W bits
     };
     if (win.apply_x == nullptr) {                                    // wave-uniform
-#pragma unroll
-        for (int b = 0; b < NR; ++b)
+        // image (h, j) starts at out + h*H + j*E, a scalar address the lane adds its 32-bit byte offset r * 4 to (saddr stores;
+        // the empty asm keeps the compiler from folding the image offset back into a 64-bit vector add per store)
+        auto store_all = [&](auto full_width) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) out[(uint64_t)(rr[b] + (uint32_t)h * H + (uint32_t)j * E)] = final_value(b, h, j);
+                for (int j = 0; j < 4; ++j) {
+                    uint64_t img_off = (uint64_t)h * H + (uint64_t)j * E;
+                    asm volatile("" : "+s"(img_off));
+                    int32_t *img = out + img_off;
+#pragma unroll
+                    for (int b = 0; b < NR; ++b) {
+                        int32_t v;
+                        if constexpr (MODE != 2 && decltype(full_width)::value) v = acc_value(acc[b][h][j]);   // W == 32: nothing to wrap
+                        else v = final_value(b, h, j);
+                        *reinterpret_cast<int32_t *>(reinterpret_cast<char *>(img) + (rr[b] << 2)) = v;
+                    }
+                }
+        };
+        if (W == 32u) store_all(std::true_type{});
+        else store_all(std::false_type{});
     } else {
         // Fused apply (emit()): one run at a time, its eight x samples fetched together before they are used
 #pragma unroll

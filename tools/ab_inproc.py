@@ -50,8 +50,12 @@ def main():
     import torch
     torch.zeros(1, device="cuda")
     libs = []
-    for i, f in enumerate(variants):
-        L = ctypes.CDLL(build_variant(i, f))
+    # AB_EXTRA_LIBS: comma-separated prebuilt libraries (e.g. an older commit built into build/ab/) timed beside the variants
+    extra = [e for e in os.environ.get("AB_EXTRA_LIBS", "").split(",") if e]
+    paths = [build_variant(i, f) for i, f in enumerate(variants)] + [os.path.join(ROOT, e) for e in extra]
+    variants = variants + ["lib:" + os.path.basename(e) for e in extra]
+    for path in paths:
+        L = ctypes.CDLL(path)
         L.bhw_generate_device.argtypes = [ctypes.POINTER(binding.BhwParams), ctypes.c_int, ctypes.c_void_p,
                                           ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
         L.bhw_params_init.argtypes = [ctypes.POINTER(binding.BhwParams), ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
