@@ -125,11 +125,11 @@ __device__ __forceinline__ T ld_off(const void *__restrict__ base, uint32_t byte
     return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 
-// FMT: -1 format read from cfg.tab_dlog at run time, 0 plain int2 entries, 1 delta16, 2 residual.
-template <int KCLASS = 0, int FMT = -1, int SPLIT = -1>
-__device__ __forceinline__ int2 tab_load(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t log2_entries)
+// Entry `u` of the table, stored at byte offset `boff`.  FMT: -1 format read from cfg.tab_dlog at run time, 0 plain int2 entries,
+// 1 delta16, 2 residual.
+template <int FMT = -1>
+__device__ __forceinline__ int2 tab_fetch(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t idx)
 {
-    const uint32_t idx = tab_index<KCLASS, SPLIT>(u, log2_entries, cfg.tab_split);
     if (FMT == 0 || (FMT < 0 && cfg.tab_dlog == 0)) return ld_off<int2>(table, idx << 3);
     if (FMT == 1 || (FMT < 0 && cfg.tab_dlog == kPackLog)) {
         const uint32_t e = ld_off<uint32_t>(table, idx << 2);
@@ -140,6 +140,51 @@ __device__ __forceinline__ int2 tab_load(const BhwCordicCfg &cfg, const void *__
     const uint32_t e = ld_off<uint16_t>(table, idx << 1);
     const int2 p = tab_predict(ld_off<int4>(cfg.tab_coarse, (u >> d) << 4), u & ((1u << d) - 1u), d);
     return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
+}
+
+template <int KCLASS = 0, int FMT = -1, int SPLIT = -1>
+__device__ __forceinline__ int2 tab_load(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t log2_entries)
+{
+    return tab_fetch<FMT>(cfg, table, u, tab_index<KCLASS, SPLIT>(u, log2_entries, cfg.tab_split));
+}
+
+// Split layout, entries of one residue class (the odd harmonics of a lane: u = K*r has r's class for every odd K, and so has
+// the half-period image u + E/2):
+//   index(u) = (u >> s) | base,   s = 1 (u odd) or 2 (u even),  base = E/2 (u odd), E/4 (u % 4 == 2), 0 (u % 4 == 0)
+// -- the regions are sized so that base never overlaps the shifted index.  The byte offset index << LB (LB = log2 of the entry
+// size) is one shift of u by |s - LB| and an OR; split_class() folds the class once per run into one word
+//   cls = (base << LB) | shift_amount          (the shift amount sits below bit LB, where byte offsets have zeros)
+// so that  byte offset = (shift(u, cls) | cls) & ~(2^LB - 1): the hardware takes the shift amount from the low five bits of cls.
+// Two instructions instead of nine per gather.
+template <int FMT>
+__device__ __forceinline__ uint32_t split_class(uint32_t r, uint32_t log2_entries)
+{
+    constexpr uint32_t LB = FMT == 2 ? 1u : FMT == 1 ? 2u : 3u;
+    const uint32_t e = 1u << log2_entries;
+    const uint32_t s = (r & 1u) ? 1u : 2u;
+    const uint32_t base = (r & 1u) ? (e >> 1) : (((r >> 1) & 1u) ? (e >> 2) : 0u);
+    const uint32_t amount = FMT == 2 ? s - 1u : LB - s;          // FMT 2: right by s - 1 (0 / 1); else left by LB - s (0 .. 2)
+    return (base << LB) | amount;
+}
+
+template <int FMT>
+__device__ __forceinline__ int2 tab_load_class(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t cls)
+{
+    if constexpr (FMT == 2) {                                    // 2 bytes per entry
+        const uint32_t boff = ((u >> (cls & 31u)) | cls) & ~1u;
+        const uint32_t d = cfg.tab_dlog;
+        const uint32_t e = ld_off<uint16_t>(table, boff);
+        const int2 p = tab_predict(ld_off<int4>(cfg.tab_coarse, (u >> d) << 4), u & ((1u << d) - 1u), d);
+        return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
+    } else if constexpr (FMT == 1) {                             // 4 bytes per entry
+        const uint32_t boff = ((u << (cls & 31u)) | cls) & ~3u;
+        const uint32_t e = ld_off<uint32_t>(table, boff);
+        const int2 base = ld_off<int2>(cfg.tab_coarse, (u >> kPackLog) << 3);
+        return make_int2(base.x + (int32_t)(int16_t)(e & 0xFFFFu), base.y + ((int32_t)e >> 16));
+    } else {                                                     // 8 bytes per entry
+        const uint32_t boff = ((u << (cls & 31u)) | cls) & ~7u;
+        return ld_off<int2>(table, boff);
+    }
 }
 
 // `head` = (c, s) of the first entry of u's 64-entry block (delta16; the caller holds it: lane 0 of the wave);
@@ -815,6 +860,9 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
         const uint32_t start = ((blockIdx.x + tp.tile0) * kLanes + tp.offs[part * NR + b]) & hmask;   // scalar; offs padded with copies of the last run
         rr[b] = (start + (lane_in_part + kLanes - (start & 63u)) % kLanes) & hmask;
     }
+    uint32_t cls[NR];                                                // residue class of r in the split layout (odd harmonics)
+#pragma unroll
+    for (int b = 0; b < NR; ++b) cls[b] = split_class<FMT>(rr[b], lq);
     acc_t acc[NR][2][4];
 #pragma unroll
     for (int b = 0; b < NR; ++b)
@@ -834,8 +882,9 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
         _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
             _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                             \
                 const uint32_t theta = (uint32_t)K * (rr[b] + (uint32_t)g * H);                          \
-                cs[b][g] = (NB > 1) ? tab_load<KC, FMT, 1>(cfg, table, theta & emask, lq)                \
-                                    : tab_load<KC, FMT, -1>(cfg, table, (theta & emask) >> cfg.z_shr, lq - cfg.z_shr); \
+                if constexpr (NB > 1 && (K & 1)) cs[b][g] = tab_load_class<FMT>(cfg, table, theta & emask, cls[b]); \
+                else cs[b][g] = (NB > 1) ? tab_load<KC, FMT, 1>(cfg, table, theta & emask, lq)           \
+                                         : tab_load<KC, FMT, -1>(cfg, table, (theta & emask) >> cfg.z_shr, lq - cfg.z_shr); \
             }                                                                                            \
         }                                                                                                \
         _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
