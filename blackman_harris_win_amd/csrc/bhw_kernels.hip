@@ -724,7 +724,10 @@ __device__ __forceinline__ int32_t w32_final(const Sum32 &acc, uint32_t W, uint3
 //         W+2-bit sum carried as 4*hi + lo (Sum32 above).
 // sv[i] = the harmonic's term for an image whose quadrant is q + i (MODE 0/1: already signed (-1)^K; MODE 2: b_k, sign applied
 // when it is accumulated)
-template <int K, int MODE>
+// QBASE / QBITS: what the caller knows about q at compile time.  A ring lane r < N/8 turns harmonic K through fewer than K/2 + 1
+// quadrants, so q - QBASE takes 1 (QBITS 0), 2 (QBITS 1) or more (QBITS 2: plain two-bit rotation, QBASE 0) values: harmonics 1 and
+// 2 need no run-time rotation at all, harmonics 3 and 4 one select per slot instead of two (ring_quadrants() below).
+template <int K, int MODE, int QBASE = 0, int QBITS = 2>
 __device__ __forceinline__ void tile_harmonic(const BhwCordicCfg &cfg, const int32_t a, const uint32_t W, const int2 cs, const uint32_t q,
                                               int32_t (&sv)[4])
 {
@@ -764,13 +767,33 @@ __device__ __forceinline__ void tile_harmonic(const BhwCordicCfg &cfg, const int
         }
     }
     // rotate the four candidates by q so that image j (quadrant q + j*K) reads a fixed slot
-    const bool b0 = q & 1u, b1 = q & 2u;
-    const int32_t r0 = b0 ? p1 : p0, r1 = b0 ? p2 : p1, r2 = b0 ? p3 : p2, r3 = b0 ? p0 : p3;
-    sv[0] = b1 ? r2 : r0;
-    sv[1] = b1 ? r3 : r1;
-    sv[2] = b1 ? r0 : r2;
-    sv[3] = b1 ? r1 : r3;
+    if constexpr (QBITS == 2) {
+        static_assert(QBASE == 0, "two-bit rotation takes q as it is");
+        const bool b0 = q & 1u, b1 = q & 2u;
+        const int32_t r0 = b0 ? p1 : p0, r1 = b0 ? p2 : p1, r2 = b0 ? p3 : p2, r3 = b0 ? p0 : p3;
+        sv[0] = b1 ? r2 : r0;
+        sv[1] = b1 ? r3 : r1;
+        sv[2] = b1 ? r0 : r2;
+        sv[3] = b1 ? r1 : r3;
+    } else {
+        const int32_t p[4] = {p0, p1, p2, p3};
+        if constexpr (QBITS == 0) {                                   // q == QBASE for every lane
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sv[i] = p[(i + QBASE) & 3];
+        } else {                                                      // q is QBASE or QBASE + 1
+            const bool b0 = ((q ^ (uint32_t)QBASE) & 1u) != 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sv[i] = b0 ? p[(i + QBASE + 1) & 3] : p[(i + QBASE) & 3];
+        }
+    }
 }
+
+// Quadrants harmonic K can be in for a ring lane r in [0, N/8) (image h: r + h * N/8): theta / (N/4) lies in [K*h/2, K*h/2 + K/2).
+// first = the lowest quadrant, count = how many (1, 2 or more).  Only the odd harmonics have an h = 1 gather.
+__host__ __device__ constexpr int ring_quadrant_first(int K, int h) { return (K * h) >> 1; }
+__host__ __device__ constexpr int ring_quadrant_count(int K, int h) { return ((K * h + K - 1) >> 1) - ((K * h) >> 1) + 1; }
+__host__ __device__ constexpr int ring_qbits(int K, int h) { return ring_quadrant_count(K, h) == 1 ? 0 : ring_quadrant_count(K, h) == 2 ? 1 : 2; }
+__host__ __device__ constexpr int ring_qbase(int K, int h) { return ring_qbits(K, h) == 2 ? 0 : (ring_quadrant_first(K, h) & 3); }
 
 // image j of a lane sits K*j quadrants after image 0; OFF = extra quadrants of this half-period image (even K: K/2)
 template <int K, int OFF>
@@ -890,10 +913,10 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
         _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
             int32_t sv[4];                                                                               \
             /* only quadrant bits 0,1 of theta >> lq are used */                                         \
-            tile_harmonic<K, MODE>(cfg, win.aa[K], W, cs[b][0], ((uint32_t)K * rr[b]) >> lq, sv);       \
+            tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0)>(cfg, win.aa[K], W, cs[b][0], ((uint32_t)K * rr[b]) >> lq, sv); \
             tile_accumulate<K, 0>(sv, acc[b][0]);                                                        \
             if constexpr (NG == 2) {                                                                     \
-                tile_harmonic<K, MODE>(cfg, win.aa[K], W, cs[b][NG - 1], ((uint32_t)K * (rr[b] + H)) >> lq, sv); \
+                tile_harmonic<K, MODE, ring_qbase(K, 1), ring_qbits(K, 1)>(cfg, win.aa[K], W, cs[b][NG - 1], ((uint32_t)K * (rr[b] + H)) >> lq, sv); \
                 tile_accumulate<K, 0>(sv, acc[b][1]);                                                    \
             } else {                                                                                     \
                 /* even K: the second half-period image reads the same entry K/2 quadrants further on */ \
@@ -1158,11 +1181,11 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win, BhwFo
         constexpr uint32_t slot = ((K - 1) / 2) * 3 + ((K & 1) ? 0 : 2);                             \
         int32_t sv[4];                                                                               \
         const int2 cs0 = chain(slot, K, 0u);                                                         \
-        tile_harmonic<K, MODE>(cfg, win.aa[K], W, cs0, ((uint32_t)K * r) >> lq, sv);                 \
+        tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0)>(cfg, win.aa[K], W, cs0, ((uint32_t)K * r) >> lq, sv); \
         tile_accumulate<K, 0>(sv, acc[0]);                                                           \
         if constexpr ((K & 1) != 0) {                                                                \
             const int2 cs1 = chain(slot + 1u, K, 1u);                                                \
-            tile_harmonic<K, MODE>(cfg, win.aa[K], W, cs1, ((uint32_t)K * (r + H)) >> lq, sv);       \
+            tile_harmonic<K, MODE, ring_qbase(K, 1), ring_qbits(K, 1)>(cfg, win.aa[K], W, cs1, ((uint32_t)K * (r + H)) >> lq, sv); \
             tile_accumulate<K, 0>(sv, acc[1]);                                                       \
         } else {                                                                                     \
             tile_accumulate<K, K / 2>(sv, acc[1]);                                                   \
