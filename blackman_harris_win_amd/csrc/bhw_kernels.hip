@@ -101,13 +101,9 @@ __device__ __forceinline__ uint32_t tab_index(uint32_t u, uint32_t log2_entries,
 //          < 1 LSB of curvature (d is chosen for that, bhwk_resid_dlog).  Two bytes per entry = that deviation for c and s;
 //          int4 records {c, s, dc, ds} at cfg.tab_coarse (16 bytes per 2^d entries).  Build and combine evaluate the same
 //          integer predictor  rec.c + ((rec.dc * (t mod 2^d)) >> d),  so the reconstruction is exact as long as the deviation
-//          fits int8 (tests/test_oracle.py::test_residual_format_margin measures <= 40 over every model and width; the build
-//          kernels check every entry of a configuration on its first use, bhw_api.cpp).  The bytes are stored biased by +128
-//          (kResidBias) and the records hold c - 128, s - 128, so that unpacking is predictor + unsigned byte: a byte select on
-//          the add (SDWA) instead of two sign-extending bit-field extracts per entry.
+//          fits int8 (tests/test_oracle.py::test_residual_format_margin measures <= 40 over every model and width).
 // The combine pass is bound by table + output traffic as much as by arithmetic, and these cut the table's share to 1/2 and 1/4.
 constexpr uint32_t kPackLog = 6;
-constexpr int32_t kResidBias = 128;      // residual format: records hold (c, s) - kResidBias, bytes hold deviation + kResidBias
 
 __device__ __forceinline__ int2 tab_predict(const int4 rec, uint32_t f, uint32_t d)
 {
@@ -143,7 +139,7 @@ __device__ __forceinline__ int2 tab_fetch(const BhwCordicCfg &cfg, const void *_
     const uint32_t d = cfg.tab_dlog;
     const uint32_t e = ld_off<uint16_t>(table, idx << 1);
     const int2 p = tab_predict(ld_off<int4>(cfg.tab_coarse, (u >> d) << 4), u & ((1u << d) - 1u), d);
-    return make_int2(p.x + (int32_t)(e & 0xFFu), p.y + (int32_t)((e >> 8) & 0xFFu));   // the records carry the -128 bias
+    return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
 }
 
 template <int KCLASS = 0, int FMT = -1, int SPLIT = -1>
@@ -179,7 +175,7 @@ __device__ __forceinline__ int2 tab_load_class(const BhwCordicCfg &cfg, const vo
         const uint32_t d = cfg.tab_dlog;
         const uint32_t e = ld_off<uint16_t>(table, boff);
         const int2 p = tab_predict(ld_off<int4>(cfg.tab_coarse, (u >> d) << 4), u & ((1u << d) - 1u), d);
-        return make_int2(p.x + (int32_t)(e & 0xFFu), p.y + (int32_t)((e >> 8) & 0xFFu));
+        return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
     } else if constexpr (FMT == 1) {                             // 4 bytes per entry
         const uint32_t boff = ((u << (cls & 31u)) | cls) & ~3u;
         const uint32_t e = ld_off<uint32_t>(table, boff);
@@ -206,9 +202,9 @@ __device__ __forceinline__ void tab_store(void *__restrict__ table, uint32_t u, 
         reinterpret_cast<uint32_t *>(table)[idx] = ((uint32_t)dc & 0xFFFFu) | ((uint32_t)ds << 16);
         if ((u & ((1u << kPackLog) - 1u)) == 0u) reinterpret_cast<int2 *>(coarse)[u >> kPackLog] = make_int2(c, s);
     } else {
-        const int2 p = tab_predict(rec, u & ((1u << dlog) - 1u), dlog);                  // rec is biased: p = prediction - 128
-        const int32_t dc = c - p.x, ds = s - p.y;                                         // deviation + 128
-        if (check_flag && (((uint32_t)dc | (uint32_t)ds) > 255u)) atomicOr(check_flag, 1u);
+        const int2 p = tab_predict(rec, u & ((1u << dlog) - 1u), dlog);
+        const int32_t dc = c - p.x, ds = s - p.y;
+        if (check_flag && !(fits_bits(dc, 8) && fits_bits(ds, 8))) atomicOr(check_flag, 1u);
         reinterpret_cast<uint16_t *>(table)[idx] = (uint16_t)(((uint32_t)dc & 0xFFu) | (((uint32_t)ds & 0xFFu) << 8));
     }
 }
@@ -455,9 +451,9 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
 
     auto record_of = [&](uint32_t cell) -> int4 {                  // cell in [cell_lo, cell_lo + n_cell)
         const uint32_t t = cell - cell_lo;
-        if (cell + 1u < cells_total) return make_int4(hc[t] - kResidBias, hs[t] - kResidBias, hc[t + 1] - hc[t], hs[t + 1] - hs[t]);
+        if (cell + 1u < cells_total) return make_int4(hc[t], hs[t], hc[t + 1] - hc[t], hs[t + 1] - hs[t]);
         const uint32_t tp = t ? t - 1u : n_cell + 1u;                // last cell of the table: slope of the cell before it
-        return make_int4(hc[t] - kResidBias, hs[t] - kResidBias, hc[t] - hc[tp], hs[t] - hs[tp]);
+        return make_int4(hc[t], hs[t], hc[t] - hc[tp], hs[t] - hs[tp]);
     };
     auto record = [&](uint32_t cell) -> int4 {                     // the same for a wave-uniform cell: scalar control flow
         return record_of(__builtin_amdgcn_readfirstlane(cell));
@@ -503,9 +499,9 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
             if (lane == 0u) reinterpret_cast<int2 *>(const_cast<void *>(plan.tab_coarse))[g] = head;   // block = group
         } else {
             const int4 rec = record((g << 6) >> d);                                                     // wave-uniform
-            const int2 p = tab_predict(rec, ((g << 6) & ((1u << d) - 1u)) + lane, d);   // biased records: prediction - 128
-            const int32_t dc = c - p.x, ds = sn - p.y;                                   // deviation + 128
-            if (plan.check_flag && (((uint32_t)dc | (uint32_t)ds) > 255u)) atomicOr(plan.check_flag, 1u);
+            const int2 p = tab_predict(rec, ((g << 6) & ((1u << d) - 1u)) + lane, d);
+            const int32_t dc = c - p.x, ds = sn - p.y;
+            if (plan.check_flag && !(fits_bits(dc, 8) && fits_bits(ds, 8))) atomicOr(plan.check_flag, 1u);
             reinterpret_cast<uint16_t *>(table)[idx] = (uint16_t)(((uint32_t)dc & 0xFFu) | (((uint32_t)ds & 0xFFu) << 8));
         }
     }
