@@ -90,6 +90,22 @@ public:
         check(bhw_apply_device(&p_, device_, stream, phase_, count, d_x, d_y, shift));
         phase_ = (phase_ + count) % length();
     }
+    // Every lazy step of later calls done now (ROM upload, scratch, packed-table verification): bhw_prepare_device.
+    void PREPARE(void *stream = nullptr) { check(bhw_prepare_device(&p_, device_, stream)); }
+    // One window over several devices without a collective: what part `part` of `n_parts` owns ...
+    std::vector<bhw_segment> SEGMENTS(uint32_t part, uint32_t n_parts) const
+    {
+        uint32_t n = 0;
+        check(bhw_part_segments(&p_, part, n_parts, nullptr, 0, &n));
+        std::vector<bhw_segment> v(n);
+        check(bhw_part_segments(&p_, part, n_parts, v.data(), n, &n));
+        return v;
+    }
+    // ... and those coefficients written into d_window, the base of a full-length (2^PHI_WIDTH) device buffer
+    void ENABLE_PART(uint32_t part, uint32_t n_parts, int32_t *d_window, void *stream = nullptr)
+    {
+        check(bhw_generate_part_device(&p_, device_, stream, part, n_parts, d_window, nullptr));
+    }
     const bhw_params &params() const { return p_; }
 
 private:

@@ -72,6 +72,13 @@ int main(int argc, char **argv)
                 raw.sin_type = BHW_SIN_TAYLOR;                 // the ABI itself refuses what the reference cannot build
                 bad += (s.params().sin_type == BHW_SIN_CORDIC && bhw_params_validate(&raw) == BHW_ERR_UNSUPPORTED);
             }
+            {   // ownership parts tile the window (host arithmetic)
+                bhw::win_selector s(20, 32, "BH7TERM");
+                uint64_t owned = 0;
+                for (uint32_t g = 0; g < 4; ++g)
+                    for (const bhw_segment &sg : s.SEGMENTS(g, 4)) owned += sg.count;
+                bad += (owned == (1ull << 20)) ? 0 : 50;
+            }
             auto z = bhw::win_function(6, 0, 8, 10, 16);   // unknown selector -> win_empty
             for (int32_t v : z) bad += (v == 0) ? 0 : 100;
             printf("%d\n", bad);

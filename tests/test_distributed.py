@@ -1,5 +1,5 @@
-"""The N>1 path on CPU (gloo, world_size 2): bench.py's shard plan, barrier/max-over-ranks protocol and the
-index-range sharding of the selector, with the oracle standing in for the GPU step."""
+"""The N>1 path on CPU (gloo, world_size 2): bench.py's shard plan, barrier/max-over-ranks protocol, the index-range sharding
+of the selector and the interleaved ownership parts (bhw_part_segments), with the oracle standing in for the GPU step."""
 import os
 import socket
 import sys
@@ -34,6 +34,16 @@ def _worker(rank, world, port, outdir):
     n0, count = shard_range(1 << 12, rank, world)
     shard = O.generate(p, n0, count)
     np.save(os.path.join(outdir, f"shard{rank}.npy"), shard)
+    # (1b) interleaved ownership of one window (bench.py --scaling strong, bhw_generate_part_device): every rank fills exactly
+    # the segments bhw_part_segments gives it -- host arithmetic of the C ABI, no GPU -- and nothing else
+    from blackman_harris_win_amd import binding as B
+    for win, pw, w in ((7, 22, 32), (4, 16, 24)):
+        bp = B.make_params(win, pw, w)
+        po = O.from_bhw(bp)
+        window = np.full(1 << pw, -1, np.int64)
+        for n0s, cnt in B.part_segments(bp, rank, world):
+            window[n0s:n0s + cnt] = O.generate_mt(po, n0s, cnt, threads=2)
+        np.save(os.path.join(outdir, f"part_{win}_{pw}_{rank}.npy"), window)
     # (2) bench.py's weak-scaling plan: rank r owns stream indices [r*2^26, (r+1)*2^26)
     b0, bc = bench.shard_for(rank)
     assert (b0, bc) == (rank << 26, 1 << 26)
@@ -67,6 +77,14 @@ def test_two_rank_gloo(tmp_path):
     whole = O.generate(O.oparams(7, 12, 32), 0, 1 << 12)
     got = np.concatenate([np.load(tmp_path / "shard0.npy"), np.load(tmp_path / "shard1.npy")])
     assert np.array_equal(got, whole)
+    # the two ranks' interleaved parts tile the window: every coefficient owned (seam overlaps agree), values exact
+    for win, pw, w in ((7, 22, 32), (4, 16, 24)):
+        a, b = (np.load(tmp_path / f"part_{win}_{pw}_{r}.npy") for r in (0, 1))
+        both = (a >= 0) & (b >= 0)
+        assert ((a >= 0) | (b >= 0)).all() and both.sum() < (1 << pw) // 100
+        assert np.array_equal(a[both], b[both])
+        full = np.where(a >= 0, a, b).astype(np.int32)
+        assert np.array_equal(full, O.generate_mt(O.oparams(win, pw, w), 0, 1 << pw))
 
 
 def test_bench_refuses_mismatched_world(monkeypatch):

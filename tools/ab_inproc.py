@@ -59,6 +59,9 @@ def main():
         L.bhw_generate_device.argtypes = [ctypes.POINTER(binding.BhwParams), ctypes.c_int, ctypes.c_void_p,
                                           ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
         L.bhw_params_init.argtypes = [ctypes.POINTER(binding.BhwParams), ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+        if hasattr(L, "bhw_generate_part_device"):
+            L.bhw_generate_part_device.argtypes = [ctypes.POINTER(binding.BhwParams), ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32,
+                                                   ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
         libs.append(L)
     n = 1 << pw
     out = torch.empty(n, dtype=torch.int32, device="cuda")
@@ -69,9 +72,17 @@ def main():
     p.combine = int(os.environ.get("AB_COMBINE", "0"))
     p.model = int(os.environ.get("AB_MODEL", "0"))
     p.lut_size = int(os.environ.get("AB_L", "9"))
+    parts = int(os.environ.get("AB_PARTS", "0"))          # AB_PARTS=G: time interleaved ownership part 1 of G instead of the whole window
+
+    def call(L):
+        if parts:
+            return L.bhw_generate_part_device(ctypes.byref(p), 0, ctypes.c_void_p(st), 1, parts, ctypes.c_void_p(out.data_ptr()), None)
+        return L.bhw_generate_device(ctypes.byref(p), 0, ctypes.c_void_p(st), 0, n, ctypes.c_void_p(out.data_ptr()))
+
     ref = None
     for L in libs:
-        rc = L.bhw_generate_device(ctypes.byref(p), 0, ctypes.c_void_p(st), 0, n, ctypes.c_void_p(out.data_ptr()))
+        out.zero_()
+        rc = call(L)
         assert rc == 0, rc
         torch.cuda.synchronize()
         if ref is None:
@@ -84,7 +95,7 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(inner):
-                L.bhw_generate_device(ctypes.byref(p), 0, ctypes.c_void_p(st), 0, n, ctypes.c_void_p(out.data_ptr()))
+                call(L)
             e1.record()
             torch.cuda.synchronize()
             if r:   # round 0 = clock ramp
