@@ -1224,7 +1224,10 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win, BhwFo
 // All sums are plain int32: HLS rule modulo 2^32 as in the tile kernel; VHDL rule needs W + 2 <= 30 bits (z_shr > 0 means
 // W < PW <= 30 anyway; the launcher checks).
 // ---------------------------------------------------------------------------------------
-constexpr int kRlRun = 16;
+#ifndef BHW_RL_RUN
+#define BHW_RL_RUN 16
+#endif
+constexpr int kRlRun = BHW_RL_RUN;               // 8 or 16 (the swizzles below assume a multiple of 4 granule rows)
 #ifndef BHW_RL_BLOCK
 #define BHW_RL_BLOCK 64
 #endif
@@ -1245,7 +1248,7 @@ __global__ __launch_bounds__(kRlBlock) void k_runlength_window(BhwCordicCfg cfg,
 {
 #if !BHW_RL_DIRECT_STORE
     using gran_t = typename std::conditional<NARROW, uint2, int4>::type;  // four coefficients: 4 x int16 or 4 x int32
-    __shared__ gran_t tile[kRlBlock / 64][4][256];                        // [wave][image j][granule]: 8 / 16 KiB per wave
+    __shared__ gran_t tile[kRlBlock / 64][4][16 * kRlRun];                        // [wave][image j][granule]: 8 / 16 KiB per wave
 #endif
     const uint32_t lq = cfg.phi_width - 2;
     const uint32_t E = 1u << lq, emask = E - 1u, H = E >> 1;
@@ -1317,13 +1320,13 @@ __global__ __launch_bounds__(kRlBlock) void k_runlength_window(BhwCordicCfg cfg,
         }
 #else
             if constexpr (NARROW) {
-                const uint32_t g = rl_swizzle16(4u * lane + (uint32_t)c4);
+                const uint32_t g = rl_swizzle16((uint32_t)(kRlRun / 4) * lane + (uint32_t)c4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     tile[wave][j][g] = make_uint2(((uint32_t)v[j][0] & 0xFFFFu) | ((uint32_t)v[j][1] << 16),
                                                   ((uint32_t)v[j][2] & 0xFFFFu) | ((uint32_t)v[j][3] << 16));
             } else {
-                const uint32_t g = rl_swizzle(4u * lane + (uint32_t)c4);
+                const uint32_t g = rl_swizzle((uint32_t)(kRlRun / 4) * lane + (uint32_t)c4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) tile[wave][j][g] = make_int4(v[j][0], v[j][1], v[j][2], v[j][3]);
             }
@@ -1333,7 +1336,7 @@ __global__ __launch_bounds__(kRlBlock) void k_runlength_window(BhwCordicCfg cfg,
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int sgrp = 0; sgrp < 4; ++sgrp) {
+            for (int sgrp = 0; sgrp < kRlRun / 4; ++sgrp) {
                 int4 d;
                 if constexpr (NARROW) {
                     const uint2 q = tile[wave][j][rl_swizzle16(64u * (uint32_t)sgrp + lane)];
