@@ -127,6 +127,14 @@ __device__ __forceinline__ T ld_off(const void *__restrict__ base, uint32_t byte
 
 // Entry `u` of the table, stored at byte offset `boff`.  FMT: -1 format read from cfg.tab_dlog at run time, 0 plain int2 entries,
 // 1 delta16, 2 residual.
+// Residual format: cell size and in-cell mask as the caller holds them.  On gfx950 a VOP2 instruction with an SGPR operand
+// issues in ~4.1 cycles against ~2.5 with VGPR / inline-constant operands (profiles/r02_ubench_gfx950.txt), so the tile
+// kernel, which shifts and masks by these per gather, keeps them in VGPRs; everyone else passes the scalars.
+struct ResidK {
+    uint32_t d;       // log2 of the cell size
+    uint32_t fmask;   // 2^d - 1
+};
+
 template <int FMT = -1>
 __device__ __forceinline__ int2 tab_fetch(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t idx)
 {
@@ -140,6 +148,17 @@ __device__ __forceinline__ int2 tab_fetch(const BhwCordicCfg &cfg, const void *_
     const uint32_t e = ld_off<uint16_t>(table, idx << 1);
     const int2 p = tab_predict(ld_off<int4>(cfg.tab_coarse, (u >> d) << 4), u & ((1u << d) - 1u), d);
     return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
+}
+
+template <int FMT>
+__device__ __forceinline__ int2 tab_fetch_k(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t idx, const ResidK &rk)
+{
+    if constexpr (FMT != 2) return tab_fetch<FMT>(cfg, table, u, idx);
+    else {
+        const uint32_t e = ld_off<uint16_t>(table, idx << 1);
+        const int2 p = tab_predict(ld_off<int4>(cfg.tab_coarse, (u >> rk.d) << 4), u & rk.fmask, rk.d);
+        return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
+    }
 }
 
 template <int KCLASS = 0, int FMT = -1, int SPLIT = -1>
@@ -168,13 +187,12 @@ __device__ __forceinline__ uint32_t split_class(uint32_t r, uint32_t log2_entrie
 }
 
 template <int FMT>
-__device__ __forceinline__ int2 tab_load_class(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t cls)
+__device__ __forceinline__ int2 tab_load_class(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t cls, const ResidK &rk)
 {
     if constexpr (FMT == 2) {                                    // 2 bytes per entry
         const uint32_t boff = ((u >> (cls & 31u)) | cls) & ~1u;
-        const uint32_t d = cfg.tab_dlog;
         const uint32_t e = ld_off<uint16_t>(table, boff);
-        const int2 p = tab_predict(ld_off<int4>(cfg.tab_coarse, (u >> d) << 4), u & ((1u << d) - 1u), d);
+        const int2 p = tab_predict(ld_off<int4>(cfg.tab_coarse, (u >> rk.d) << 4), u & rk.fmask, rk.d);
         return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
     } else if constexpr (FMT == 1) {                             // 4 bytes per entry
         const uint32_t boff = ((u << (cls & 31u)) | cls) & ~3u;
@@ -883,6 +901,14 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
         const uint32_t start = ((blockIdx.x + tp.tile0) * kLanes + tp.offs[part * NR + b]) & hmask;   // scalar; offs padded with copies of the last run
         rr[b] = (start + (lane_in_part + kLanes - (start & 63u)) % kLanes) & hmask;
     }
+#ifndef BHW_TILE_VGPR_CONSTS
+#define BHW_TILE_VGPR_CONSTS 1
+#endif
+    ResidK rk{cfg.tab_dlog, (1u << cfg.tab_dlog) - 1u};
+    uint32_t emask_v = emask, lq_v = lq;                            // per-gather shift / mask operands: VGPR copies (see ResidK)
+#if BHW_TILE_VGPR_CONSTS
+    asm volatile("" : "+v"(rk.d), "+v"(rk.fmask), "+v"(emask_v), "+v"(lq_v));
+#endif
     uint32_t cls[NR];                                                // residue class of r in the split layout (odd harmonics)
 #pragma unroll
     for (int b = 0; b < NR; ++b) cls[b] = split_class<FMT>(rr[b], lq);
@@ -905,18 +931,20 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
         _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
             _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                             \
                 const uint32_t theta = (uint32_t)K * (rr[b] + (uint32_t)g * H);                          \
-                if constexpr (NB > 1 && (K & 1)) cs[b][g] = tab_load_class<FMT>(cfg, table, theta & emask, cls[b]); \
-                else cs[b][g] = (NB > 1) ? tab_load<KC, FMT, 1>(cfg, table, theta & emask, lq)           \
-                                         : tab_load<KC, FMT, -1>(cfg, table, (theta & emask) >> cfg.z_shr, lq - cfg.z_shr); \
+                if constexpr (NB > 1 && (K & 1)) cs[b][g] = tab_load_class<FMT>(cfg, table, theta & emask_v, cls[b], rk); \
+                else if constexpr (NB > 1) {                                                             \
+                    const uint32_t u = theta & emask_v;                                                  \
+                    cs[b][g] = tab_fetch_k<FMT>(cfg, table, u, tab_index<KC, 1>(u, lq, 1u), rk);         \
+                } else cs[b][g] = tab_load<KC, FMT, -1>(cfg, table, (theta & emask) >> cfg.z_shr, lq - cfg.z_shr); \
             }                                                                                            \
         }                                                                                                \
         _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
             int32_t sv[4];                                                                               \
             /* only quadrant bits 0,1 of theta >> lq are used */                                         \
-            tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0)>(cfg, win.aa[K], W, cs[b][0], ((uint32_t)K * rr[b]) >> lq, sv); \
+            tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0)>(cfg, win.aa[K], W, cs[b][0], ((uint32_t)K * rr[b]) >> lq_v, sv); \
             tile_accumulate<K, 0>(sv, acc[b][0]);                                                        \
             if constexpr (NG == 2) {                                                                     \
-                tile_harmonic<K, MODE, ring_qbase(K, 1), ring_qbits(K, 1)>(cfg, win.aa[K], W, cs[b][NG - 1], ((uint32_t)K * (rr[b] + H)) >> lq, sv); \
+                tile_harmonic<K, MODE, ring_qbase(K, 1), ring_qbits(K, 1)>(cfg, win.aa[K], W, cs[b][NG - 1], ((uint32_t)K * (rr[b] + H)) >> lq_v, sv); \
                 tile_accumulate<K, 0>(sv, acc[b][1]);                                                    \
             } else {                                                                                     \
                 /* even K: the second half-period image reads the same entry K/2 quadrants further on */ \

@@ -97,6 +97,56 @@ __global__ __launch_bounds__(256) void k_valu(int *out, int seed)
 #define S(n) asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(a##n) : "v"(b));
             OP8(S) OP8(S)
 #undef S
+        } else if constexpr (OP == 20) {  // v_add_u32 with an SGPR operand
+#define S(n) asm volatile("v_add_u32 %0, %1, %0" : "+v"(a##n) : "s"(seed));
+            OP8(S) OP8(S)
+#undef S
+        } else if constexpr (OP == 21) {  // v_ashrrev_i32 by an SGPR amount
+#define S(n) asm volatile("v_ashrrev_i32 %0, %1, %0" : "+v"(a##n) : "s"(seed));
+            OP8(S) OP8(S)
+#undef S
+        } else if constexpr (OP == 22) {  // v_and_b32 with an SGPR mask
+#define S(n) asm volatile("v_and_b32 %0, %1, %0" : "+v"(a##n) : "s"(seed));
+            OP8(S) OP8(S)
+#undef S
+        } else if constexpr (OP == 23) {  // v_mad_i64_i32 with an SGPR multiplicand
+#define S(n) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(w##n) : "s"(seed), "v"(c) : "vcc");
+            OP8(S) OP8(S)
+#undef S
+        } else if constexpr (OP == 24) {  // v_cndmask_b32 with an SGPR-pair mask (VOP3 encoding)
+            const unsigned long long m64 = 0x5555555555555555ull * (unsigned long long)seed;
+#define S(n) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a##n) : "v"(b), "s"(m64));
+            OP8(S) OP8(S)
+#undef S
+        } else if constexpr (OP == 25) {  // v_readlane_b32 -> SGPR -> dependent v_add
+#define S(n) asm volatile("v_readlane_b32 s20, %0, 5\n\tv_add_u32 %0, s20, %0" : "+v"(a##n) : : "s20");
+            OP8(S)
+#undef S
+        } else if constexpr (OP == 26) {  // v_bfe_u32
+#define S(n) asm volatile("v_bfe_u32 %0, %0, 3, 20" : "+v"(a##n));
+            OP8(S) OP8(S)
+#undef S
+        } else if constexpr (OP == 27) {  // v_bitop3_b32
+#define S(n) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x6c" : "+v"(a##n) : "v"(b), "v"(c));
+            OP8(S) OP8(S)
+#undef S
+        } else if constexpr (OP == 28) {  // v_mad_i32_i24 with an SGPR operand
+#define S(n) asm volatile("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(a##n) : "s"(seed), "v"(c));
+            OP8(S) OP8(S)
+#undef S
+        } else if constexpr (OP == 29) {  // v_alignbit_b32 with an SGPR shift amount
+#define S(n) asm volatile("v_alignbit_b32 %0, %1, %0, %2" : "+v"(a##n) : "v"(b), "s"(seed));
+            OP8(S) OP8(S)
+#undef S
+        } else if constexpr (OP == 30) {  // v_cndmask_b32 (vcc) after one v_cmp: plain VOP2 selects
+            asm volatile("v_cmp_lt_i32 vcc, %0, %1" : : "v"(a0), "v"(b) : "vcc");
+#define S(n) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a##n) : "v"(b) : "vcc");
+            OP8(S) OP8(S)
+#undef S
+        } else if constexpr (OP == 31) {  // v_sub_u32 (VGPR operands)
+#define S(n) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a##n) : "v"(b));
+            OP8(S) OP8(S)
+#undef S
         } else if constexpr (OP == 19) {  // ds_read_b32 broadcast + v_add
             __shared__ int lds[64];
             if (i == 0) lds[threadIdx.x & 63] = seed;
@@ -173,6 +223,10 @@ int main()
         {"v_and_b32", k_valu<12>, 16}, {"v_sub_u32 sgpr", k_valu<13>, 16}, {"v_cmp+v_cndmask pair", k_valu<14>, 16},
         {"v_lshl_add_u32", k_valu<15>, 16}, {"v_mad_u32_u24", k_valu<16>, 16}, {"v_bfe_i32", k_valu<17>, 16},
         {"v_mul_i32_i24", k_valu<18>, 16}, {"lds bcast + add", k_valu<19>, 16},
+        {"v_add_u32 sgpr", k_valu<20>, 16}, {"v_ashrrev_i32 sgpr", k_valu<21>, 16}, {"v_and_b32 sgpr", k_valu<22>, 16},
+        {"v_mad_i64_i32 sgpr", k_valu<23>, 16}, {"v_cndmask_b32 sgpr-pair", k_valu<24>, 16}, {"v_readlane + v_add sgpr", k_valu<25>, 16},
+        {"v_bfe_u32", k_valu<26>, 16}, {"v_bitop3_b32", k_valu<27>, 16}, {"v_mad_i32_i24 sgpr", k_valu<28>, 16},
+        {"v_alignbit_b32 sgpr", k_valu<29>, 16}, {"v_cndmask_b32 vcc (1 cmp)", k_valu<30>, 16}, {"v_sub_u32 vgpr", k_valu<31>, 16},
     };
     const int blocks = prop.multiProcessorCount * 8;
     printf("\n%-24s %10s %14s %12s\n", "instruction", "ms", "Tops/s(lane)", "cyc/wave-instr/SIMD@2.4GHz");
