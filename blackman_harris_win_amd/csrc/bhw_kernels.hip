@@ -902,7 +902,7 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
         rr[b] = (start + (lane_in_part + kLanes - (start & 63u)) % kLanes) & hmask;
     }
 #ifndef BHW_TILE_VGPR_CONSTS
-#define BHW_TILE_VGPR_CONSTS 1
+#define BHW_TILE_VGPR_CONSTS 0      // measured: 1 is 1 % slower (profiles/r02_ab_tile_kernel_steps.txt) -- register pressure outweighs the cheaper operands
 #endif
     ResidK rk{cfg.tab_dlog, (1u << cfg.tab_dlog) - 1u};
     uint32_t emask_v = emask, lq_v = lq;                            // per-gather shift / mask operands: VGPR copies (see ResidK)
