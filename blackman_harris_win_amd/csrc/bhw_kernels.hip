@@ -1233,6 +1233,158 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win, BhwFo
         }
 }
 
+// Fused fold kernel, short-launch form: the chains of 64 ring lanes SPLIT OVER THE FOUR WAVES of a workgroup (one per SIMD).
+// A launch of a few thousand lanes is bound by the serial depth of one wave -- prefix, then 5 .. 9 chains -- not by issue
+// slots; here wave w takes chains w, w + 4, w + 8 of the same 64 lanes (at most three), runs their prefixes in its first lanes,
+// broadcasts them with v_readlane (no LDS, no barrier), walks them together from the earliest split level (each chain joining
+// at its own), and hands the (c, s) pairs over through LDS; waves 0 and 1 then sum the h = 0 / h = 1 images.
+// The z recurrence takes the short path z += sg * (-lut) (sign, or, mad: three dependent instructions instead of four).
+template <bool MAD24>
+__device__ __forceinline__ void rot_step_lat(int64_t &x, int64_t &y, int32_t &z, int k, int32_t nlutk)
+{
+    const int32_t sg = (z >> 31) | 1;
+    int32_t ys = (int32_t)__builtin_amdgcn_alignbit((uint32_t)((uint64_t)y >> 32), (uint32_t)y, (uint32_t)k);
+    int32_t xs = (int32_t)__builtin_amdgcn_alignbit((uint32_t)((uint64_t)x >> 32), (uint32_t)x, (uint32_t)k);
+    asm volatile("" : "+v"(ys), "+v"(xs));
+    if constexpr (MAD24) z += __mul24(sg, nlutk);                // |lut[k]| < 2^23 from rotation kMad24From on
+    else z += sg * nlutk;                                        // 32-bit product: exact modulo 2^32 for every ROM word
+    x -= (int64_t)sg * (int64_t)ys;
+    y += (int64_t)sg * (int64_t)xs;
+}
+
+template <int NTERMS, int MODE>
+__global__ __launch_bounds__(256) void k_fold_split(BhwWinCfg win, BhwFoldPlan plan, int32_t *__restrict__ out)
+{
+    using acc_t = typename std::conditional<MODE == 2, Sum32, int32_t>::type;
+    constexpr int NCH = fold_chains(NTERMS);
+    constexpr int MAXC = (NCH + 3) / 4;                                   // chains per wave
+    __shared__ int2 cs_s[NCH][64];
+    BhwCordicCfg cfg;                                                     // tile_harmonic() reads ones_neg only
+    cfg.ones_neg = plan.ones_neg;
+    const uint32_t lq = plan.phi_width - 2;
+    const uint32_t E = 1u << lq, emask = E - 1u, H = E >> 1;
+    const uint32_t W = plan.dat_width;
+    const int n_iter = (int)plan.n_iter;
+    uint32_t run = 0;
+    while (run + 1u < plan.n_runs && blockIdx.x >= plan.wg_first[run + 1u]) ++run;
+    const uint32_t wg_r0 = plan.r0[run] + (blockIdx.x - plan.wg_first[run]) * 64u;      // 64 ring lanes per workgroup
+    const uint32_t r_end = plan.r_end[run];
+    const uint32_t z_shr = plan.z_shr, z_shl = plan.z_shl, out_shr = plan.out_shr;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t r = wg_r0 + lane;
+    const int32_t nlutv = -(int32_t)plan.lut[lane & 31u];                 // lane k holds -lut[k]
+
+    auto chain_K = [](uint32_t c) { return 2u * (c / 3u) + 1u + (c % 3u == 2u ? 1u : 0u); };
+    auto chain_h = [](uint32_t c) { return (c % 3u == 1u) ? 1u : 0u; };
+
+    // ---- phase 1: lane i < MAXC runs the shared prefix of this wave's chain i (chain index wave + 4 i) ----
+    int64_t px = plan.x0, py = plan.x0;
+    uint32_t pdz = 0u;
+    int pk = 1;
+    {
+        const uint32_t ci = lane < (uint32_t)MAXC ? lane : 0u;
+        uint32_t c = wave + 4u * ci;
+        if (c >= (uint32_t)NCH) c = wave < (uint32_t)NCH ? wave : 0u;     // idle lanes / waves repeat a valid chain
+        const uint32_t K = chain_K(c), hodd = chain_h(c);
+        const uint32_t t0 = (K * wg_r0 + hodd * H) & emask;
+        const uint32_t tl = t0 + 63u * K;
+        const uint32_t z0f = (t0 >> z_shr) << z_shl;
+        bool live = tl <= emask;
+        const uint32_t span = live ? ((tl >> z_shr) << z_shl) - z0f : 0u;
+        int32_t zf = (int32_t)(z0f - plan.lut[0]);
+        constexpr int kmax = kPrefixMax < 32 ? kPrefixMax : 32;
+#pragma unroll
+        for (int kk = 1; kk < kmax; ++kk) {
+            if (live && kk < n_iter) {
+                const int32_t zl = (int32_t)((uint32_t)zf + span);
+                if ((zf < 0) != (zl < 0)) {
+                    live = false;
+                } else {
+                    rot_step(px, py, zf, kk, plan.lut[kk]);
+                    pk = kk + 1;
+                }
+            }
+        }
+        pdz = (uint32_t)zf - z0f;
+    }
+    // ---- phase 2: this wave's chains, every lane its own leaf ----
+    int64_t x[MAXC], y[MAXC];
+    int32_t z[MAXC];
+    int k0[MAXC];
+    int kc = 32;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const uint32_t c = wave + 4u * (uint32_t)i;
+        const uint32_t cc = c < (uint32_t)NCH ? c : 0u;
+        const uint32_t xl = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)px, i), xh = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)px >> 32), i);
+        const uint32_t yl = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)py, i), yh = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)py >> 32), i);
+        x[i] = (int64_t)(((uint64_t)xh << 32) | xl);
+        y[i] = (int64_t)(((uint64_t)yh << 32) | yl);
+        const uint32_t dz = (uint32_t)__builtin_amdgcn_readlane((int)pdz, i);
+        k0[i] = c < (uint32_t)NCH ? __builtin_amdgcn_readlane(pk, i) : 32;     // chains this wave does not have never start
+        const uint32_t t = (chain_K(cc) * r + chain_h(cc) * H) & emask;
+        z[i] = (int32_t)(((t >> z_shr) << z_shl) + dz);
+        kc = k0[i] < kc ? k0[i] : kc;
+    }
+    int k = kc;
+#pragma unroll 1
+    for (; k < n_iter && k < kMad24From; ++k) {
+        const int32_t nlutk = __builtin_amdgcn_readlane(nlutv, k);
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i)
+            if (k >= k0[i]) rot_step_lat<false>(x[i], y[i], z[i], k, nlutk);   // scalar guard: k0 is wave-uniform
+    }
+#pragma unroll 1
+    for (; k < n_iter; ++k) {
+        const int32_t nlutk = __builtin_amdgcn_readlane(nlutv, k);
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i)
+            if (k >= k0[i]) rot_step_lat<true>(x[i], y[i], z[i], k, nlutk);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const uint32_t c = wave + 4u * (uint32_t)i;
+        if (c < (uint32_t)NCH) cs_s[c][lane] = make_int2((int32_t)(x[i] >> out_shr), (int32_t)(y[i] >> out_shr));
+    }
+    __syncthreads();
+    if (wave >= 2u || r >= r_end) return;
+
+    // ---- combine: wave h sums the four images n = r + h*N/8 + j*N/4 ----
+    auto combine = [&](auto hc) {
+        constexpr int HH = decltype(hc)::value;
+        acc_t acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (MODE == 2) acc[j] = Sum32{win.aa[0] >> 2, win.aa[0] & 3};
+            else acc[j] = win.aa[0];
+        }
+#define BHW_FS_HARMONIC(K)                                                                                            \
+        if constexpr (NTERMS > K) {                                                                                   \
+            constexpr uint32_t slot = ((K - 1) / 2) * 3 + ((K & 1) ? (uint32_t)HH : 2u);                              \
+            int32_t sv[4];                                                                                            \
+            if constexpr ((K & 1) != 0) {                                                                             \
+                tile_harmonic<K, MODE, ring_qbase(K, HH), ring_qbits(K, HH)>(cfg, win.aa[K], W, cs_s[slot][lane],     \
+                                                                            ((uint32_t)K * (r + (uint32_t)HH * H)) >> lq, sv); \
+                tile_accumulate<K, 0>(sv, acc);                                                                       \
+            } else {                                                                                                  \
+                tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0)>(cfg, win.aa[K], W, cs_s[slot][lane], ((uint32_t)K * r) >> lq, sv); \
+                tile_accumulate<K, (HH ? K / 2 : 0)>(sv, acc);                                                        \
+            }                                                                                                         \
+        }
+        BHW_FS_HARMONIC(1) BHW_FS_HARMONIC(2) BHW_FS_HARMONIC(3) BHW_FS_HARMONIC(4) BHW_FS_HARMONIC(5) BHW_FS_HARMONIC(6)
+#undef BHW_FS_HARMONIC
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int32_t v;
+            if constexpr (MODE == 2) v = w32_final<BHW_COMBINE_VHDL>(acc[j], W, NTERMS);
+            else v = (int32_t)((uint32_t)acc[j] << (32u - W)) >> (32u - W);
+            emit(win, out, (uint64_t)(r + (uint32_t)HH * H) + (uint64_t)j * E, v);
+        }
+    };
+    if (wave == 0u) combine(std::integral_constant<int, 0>{});
+    else combine(std::integral_constant<int, 1>{});
+}
+
 // ---------------------------------------------------------------------------------------
 // Run-length kernel: whole periods of configurations that drop phase bits (z_shr > 0).
 //
@@ -2104,9 +2256,24 @@ int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg 
 #define BHW_FD_LOCKSTEP_MAX (1u << 18)
 #endif
     const bool lockstep = total <= BHW_FD_LOCKSTEP_MAX;
+    // short launches, form of the kernel: 2 = chains split over four waves per 64 lanes (k_fold_split), 1 = lockstep, 0 = sequential
+#ifndef BHW_FD_SMALL_MODE
+#define BHW_FD_SMALL_MODE 2
+#endif
+    dim3 grid_s(0), blk_s(256);
+    if (lockstep && BHW_FD_SMALL_MODE == 2) {
+        uint32_t wgs = 0;
+        for (uint32_t i = 0; i < n_runs; ++i) {
+            plan.wg_first[i] = wgs;
+            wgs += (runs[i].r_end - runs[i].r0 + 63u) / 64u;
+        }
+        plan.wg_first[n_runs] = wgs;
+        grid_s = dim3(wgs);
+    }
 #define BHW_FD_NT_M(NT, M)                                                                                  \
     do {                                                                                                    \
-        if (lockstep) BHW_LAUNCH((k_fold_direct<NT, M, true>), grid, blk, 0, st, w, plan, d_out);           \
+        if (lockstep && BHW_FD_SMALL_MODE == 2) BHW_LAUNCH((k_fold_split<NT, M>), grid_s, blk_s, 0, st, w, plan, d_out); \
+        else if (lockstep && BHW_FD_SMALL_MODE == 1) BHW_LAUNCH((k_fold_direct<NT, M, true>), grid, blk, 0, st, w, plan, d_out); \
         else          BHW_LAUNCH((k_fold_direct<NT, M, false>), grid, blk, 0, st, w, plan, d_out);          \
     } while (0)
 #define BHW_FD_NT(NT)                                                                                       \
