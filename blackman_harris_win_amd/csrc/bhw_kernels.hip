@@ -2260,8 +2260,14 @@ int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg 
 #ifndef BHW_FD_SMALL_MODE
 #define BHW_FD_SMALL_MODE 2
 #endif
+    // measured per call (profiles/r02_ab_fused_lockstep.txt): split 7.8 / lockstep 9.0 us at 2^13 lanes (BH-7 2^16), 6.9 / 7.7 at
+    // 2^15 (BH-5 2^18), 9.7 / 9.7 at 2^16, 9.0 / 8.2 at 2^17 (BH-4 2^20): split up to 2^15 lanes, lockstep up to 2^18
+#ifndef BHW_FD_SPLIT_MAX
+#define BHW_FD_SPLIT_MAX (1u << 15)
+#endif
+    const bool split = BHW_FD_SMALL_MODE == 2 && total <= BHW_FD_SPLIT_MAX;
     dim3 grid_s(0), blk_s(256);
-    if (lockstep && BHW_FD_SMALL_MODE == 2) {
+    if (split) {
         uint32_t wgs = 0;
         for (uint32_t i = 0; i < n_runs; ++i) {
             plan.wg_first[i] = wgs;
@@ -2272,8 +2278,8 @@ int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg 
     }
 #define BHW_FD_NT_M(NT, M)                                                                                  \
     do {                                                                                                    \
-        if (lockstep && BHW_FD_SMALL_MODE == 2) BHW_LAUNCH((k_fold_split<NT, M>), grid_s, blk_s, 0, st, w, plan, d_out); \
-        else if (lockstep && BHW_FD_SMALL_MODE == 1) BHW_LAUNCH((k_fold_direct<NT, M, true>), grid, blk, 0, st, w, plan, d_out); \
+        if (split) BHW_LAUNCH((k_fold_split<NT, M>), grid_s, blk_s, 0, st, w, plan, d_out);               \
+        else if (lockstep && BHW_FD_SMALL_MODE >= 1) BHW_LAUNCH((k_fold_direct<NT, M, true>), grid, blk, 0, st, w, plan, d_out); \
         else          BHW_LAUNCH((k_fold_direct<NT, M, false>), grid, blk, 0, st, w, plan, d_out);          \
     } while (0)
 #define BHW_FD_NT(NT)                                                                                       \
