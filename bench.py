@@ -151,6 +151,7 @@ def main():
                          "(interleaved ownership parts, BASELINE config C5)")
     ap.add_argument("--algo", default="auto", choices=["auto", "direct", "table", "fused"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpp-leg", action="store_true", help="skip the extra model-cpp leg (profiling passes: only the headline kernels run)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--ramp-seconds", type=float, default=1.0, help="untimed back-to-back steps before the warmup (clock ramp)")
@@ -310,7 +311,7 @@ def main():
     # the same step with the cpp model's cosines (cpp/cordic_sincos.cpp: the bit-model pinned by the reference's own compiled
     # cordic(), tests/test_gpu_reference_pin.py) -- untimed extra leg, so the pinned model's rate is in the record too
     cpp_leg = None
-    if not strong and rank == 0:
+    if not strong and rank == 0 and not args.no_cpp_leg:
         pc = bhw.make_params(WIN, PHI_WIDTH, DAT_WIDTH, model=B.MODEL_CPP)
 
         def step_cpp():

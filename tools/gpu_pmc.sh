@@ -8,14 +8,15 @@ i=0
 for set in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM" "GRBM_GUI_ACTIVE TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
   i=$((i+1))
   rm -rf gpurun_out/pmc_${tag}_$i
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc_${tag}_$i -- python bench.py --steps 3 --warmup 1 --ramp-seconds 0.2 --no-cpu-baseline > gpurun_out/pmc_${tag}_$i.json 2> gpurun_out/pmc_${tag}_$i.err || echo "pass $i failed"
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc_${tag}_$i -- python bench.py --steps 3 --warmup 1 --ramp-seconds 0.2 --no-cpu-baseline --no-cpp-leg > gpurun_out/pmc_${tag}_$i.json 2> gpurun_out/pmc_${tag}_$i.err || echo "pass $i failed"
 done
 python - <<PY
 import csv,glob,collections
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_${tag}_*/*/*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
-        agg[row["Kernel_Name"][:48]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        name = row["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(")[0]      # kernel<template args>
+        agg[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 import json
 summary={}
 for k,v in agg.items():
@@ -38,7 +39,7 @@ import datetime, sys, os
 sys.path.insert(0, os.getcwd())
 import bench
 summary["_meta"]={"date": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"), "sources_sha16": bench.sources_sha16(),
-                  "command": "rocprofv3 --kernel-trace --pmc <set> -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline (5 passes)"}
+                  "command": "rocprofv3 --kernel-trace --pmc <set> -- python bench.py --steps 3 --warmup 1 --ramp-seconds 0.2 --no-cpu-baseline --no-cpp-leg (5 passes)"}
 json.dump(summary,open("gpurun_out/pmc_summary_${tag}.json","w"),indent=1,sort_keys=True)
 json.dump(summary,open("gpurun_out/pmc_latest.json","w"),indent=1,sort_keys=True)
 print("step HBM bytes: %.1f MB" % (step/1e6))
