@@ -893,12 +893,23 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
     // Rotating the lanes by the start's offset inside a 64-element block gives every wave an aligned block instead; only
     // wave 0 is split (head of the first block + tail of the last).  Same set of r, same gathers, full-line stores:
     // -1.25 % on the whole call (profiles/r01_ab_inproc.txt).
+    // Workgroups are dealt round-robin over the 8 XCDs (block b and b + 8 share an L2).  BHW_TILE_XCD = 1 renumbers the tiles so
+    // that each XCD sweeps a contiguous eighth of the ring (neighbouring tiles share table lines at their run boundaries and the
+    // 16-byte records of the residual format).
+#ifndef BHW_TILE_XCD
+#define BHW_TILE_XCD 1
+#endif
+    uint32_t tile_of_block = blockIdx.x;
+    if (BHW_TILE_XCD) {
+        const uint32_t per = gridDim.x >> 3, main = per << 3;       // tiles per XCD in the evenly divisible part
+        if (blockIdx.x < main) tile_of_block = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    }
     const uint32_t part = __builtin_amdgcn_readfirstlane(threadIdx.x / kLanes);   // wave-uniform: kLanes is a multiple of 64
     const uint32_t lane_in_part = threadIdx.x % kLanes;
     uint32_t rr[NR];
 #pragma unroll
     for (int b = 0; b < NR; ++b) {
-        const uint32_t start = ((blockIdx.x + tp.tile0) * kLanes + tp.offs[part * NR + b]) & hmask;   // scalar; offs padded with copies of the last run
+        const uint32_t start = ((tile_of_block + tp.tile0) * kLanes + tp.offs[part * NR + b]) & hmask;   // scalar; offs padded with copies of the last run
         rr[b] = (start + (lane_in_part + kLanes - (start & 63u)) % kLanes) & hmask;
     }
 #ifndef BHW_TILE_VGPR_CONSTS
