@@ -745,12 +745,28 @@ __device__ __forceinline__ int32_t w32_final(const Sum32 &acc, uint32_t W, uint3
 // QBASE / QBITS: what the caller knows about q at compile time.  A ring lane r < N/8 turns harmonic K through fewer than K/2 + 1
 // quadrants, so q - QBASE takes 1 (QBITS 0), 2 (QBITS 1) or more (QBITS 2: plain two-bit rotation, QBASE 0) values: harmonics 1 and
 // 2 need no run-time rotation at all, harmonics 3 and 4 one select per slot instead of two (ring_quadrants() below).
-template <int K, int MODE, int QBASE = 0, int QBITS = 2>
+// FAST (HLS rule only): every |a_k| < 2^(W-3), so a_k << (34 - W) fits int32 and  (a_k * v) >> (W-2)  is the high half of the
+// 32 x 32 product of that pre-shifted weight -- one v_mul_hi_i32 instead of v_mad_i64_i32 + v_ashrrev_i64, the low half telling
+// whether the shifted-out bits were zero.  The caller passes the pre-shifted weight as `a`.
+template <int K, int MODE, int QBASE = 0, int QBITS = 2, bool FAST = false>
 __device__ __forceinline__ void tile_harmonic(const BhwCordicCfg &cfg, const int32_t a, const uint32_t W, const int2 cs, const uint32_t q,
                                               int32_t (&sv)[4])
 {
     int32_t p0, p1, p2, p3;                                // cosine term in quadrant 0..3: c, -s, -c, s
-    if constexpr (MODE == 2) {
+    if constexpr (FAST && MODE == 1) {
+        const int32_t m0 = __mulhi(a, cs.x), m1 = __mulhi(a, ~cs.y), m2 = __mulhi(a, ~cs.x), m3 = __mulhi(a, cs.y);
+        p0 = (K & 1) ? -m0 : m0;
+        p1 = (K & 1) ? -m1 : m1;
+        p2 = (K & 1) ? -m2 : m2;
+        p3 = (K & 1) ? -m3 : m3;
+    } else if constexpr (FAST && MODE == 0) {
+        const int32_t mc = __mulhi(a, cs.x), ms = __mulhi(a, cs.y);
+        const int32_t uc = mc + (((uint32_t)a * (uint32_t)cs.x) != 0u), us = ms + (((uint32_t)a * (uint32_t)cs.y) != 0u);
+        p0 = (K & 1) ? -mc : mc;
+        p1 = (K & 1) ? us : -us;
+        p2 = (K & 1) ? uc : -uc;
+        p3 = (K & 1) ? -ms : ms;
+    } else if constexpr (MODE == 2) {
         const int32_t nc = cfg.ones_neg ? ~cs.x : -cs.x;
         const int32_t ns = cfg.ones_neg ? ~cs.y : -cs.y;
         auto slice_round = [&](int32_t v) -> int32_t {     // bh_win_7term.vhd:353-402 on the 2W-bit product (see Sum32)
@@ -876,7 +892,7 @@ __global__ __launch_bounds__(kBlock) void k_table_combine_fold_t(BhwCordicCfg cf
 // Lane r in [0, E/2) owns the eight coefficients n = r + h*E/2 + j*E (h = 0,1; j = 0..3).  For even k the
 // two h-images share one gather (k*E/2 is a whole number of quadrants); for odd k the second image reads
 // entry t + E/2, another dense span of the same tile.
-template <int NB, int MODE, int FMT>
+template <int NB, int MODE, int FMT, bool FAST = false>
 __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 4 : BHW_TILE_WAVES))) void k_table_combine_tile(BhwCordicCfg cfg, BhwWinCfg win, BhwTilePlan tp,
                                                                       const void *__restrict__ table, int32_t *__restrict__ out)
 {
@@ -952,10 +968,11 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
         _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
             int32_t sv[4];                                                                               \
             /* only quadrant bits 0,1 of theta >> lq are used */                                         \
-            tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0)>(cfg, win.aa[K], W, cs[b][0], ((uint32_t)K * rr[b]) >> lq_v, sv); \
+            const int32_t aK = FAST ? (int32_t)((uint32_t)win.aa[K] << (34u - W)) : win.aa[K];          \
+            tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0), FAST>(cfg, aK, W, cs[b][0], ((uint32_t)K * rr[b]) >> lq_v, sv); \
             tile_accumulate<K, 0>(sv, acc[b][0]);                                                        \
             if constexpr (NG == 2) {                                                                     \
-                tile_harmonic<K, MODE, ring_qbase(K, 1), ring_qbits(K, 1)>(cfg, win.aa[K], W, cs[b][NG - 1], ((uint32_t)K * (rr[b] + H)) >> lq_v, sv); \
+                tile_harmonic<K, MODE, ring_qbase(K, 1), ring_qbits(K, 1), FAST>(cfg, aK, W, cs[b][NG - 1], ((uint32_t)K * (rr[b] + H)) >> lq_v, sv); \
                 tile_accumulate<K, 0>(sv, acc[b][1]);                                                    \
             } else {                                                                                     \
                 /* even K: the second half-period image reads the same entry K/2 quadrants further on */ \
@@ -2142,11 +2159,26 @@ int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c, con
     tp.tile0 = tile0;
     const int mode = (w.combine != BHW_COMBINE_HLS) ? 2 : (c.ones_neg ? 1 : 0);
     const dim3 grid(tile_count), block(kTileThreads);
+    // one-instruction products (tile_harmonic FAST): HLS rule, 15-run tiles, every harmonic weight below 2^(W-3) in magnitude
+    // (the built-in weights are: a_k <= 0.49 * 2^(W-1 or W-2)); caller-scaled weights beyond that take the 64-bit products
+#ifndef BHW_TILE_FASTMUL
+#define BHW_TILE_FASTMUL 1
+#endif
+    bool fast = BHW_TILE_FASTMUL && mode != 2 && nb == 15 && c.dat_width >= 3;
+    for (uint32_t k = 1; k < w.n_terms && fast; ++k) {
+        const int64_t lim = (int64_t)1 << (c.dat_width - 3);
+        fast = (int64_t)w.aa[k] < lim && (int64_t)w.aa[k] >= -lim;
+    }
+#define BHW_LAUNCH_TILE_MF(NB, M, F)                                                                                     \
+    do {                                                                                                                 \
+        if (c.tab_dlog == 0)             BHW_LAUNCH((k_table_combine_tile<NB, M, 0, F>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
+        else if (c.tab_dlog == kPackLog) BHW_LAUNCH((k_table_combine_tile<NB, M, 1, F>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
+        else                             BHW_LAUNCH((k_table_combine_tile<NB, M, 2, F>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
+    } while (0)
 #define BHW_LAUNCH_TILE_M(NB, M)                                                                                         \
     do {                                                                                                                 \
-        if (c.tab_dlog == 0)             BHW_LAUNCH((k_table_combine_tile<NB, M, 0>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
-        else if (c.tab_dlog == kPackLog) BHW_LAUNCH((k_table_combine_tile<NB, M, 1>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
-        else                             BHW_LAUNCH((k_table_combine_tile<NB, M, 2>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
+        if (NB == 15 && M != 2 && fast) BHW_LAUNCH_TILE_MF(NB, M, (NB == 15 && M != 2));                                 \
+        else                            BHW_LAUNCH_TILE_MF(NB, M, false);                                                \
     } while (0)
 #define BHW_LAUNCH_TILE(NB)                                                                                              \
     do {                                                                                                                 \
@@ -2158,6 +2190,7 @@ int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c, con
     else if (nb == 3) BHW_LAUNCH_TILE(3);
     else BHW_LAUNCH_TILE(1);
 #undef BHW_LAUNCH_TILE_M
+#undef BHW_LAUNCH_TILE_MF
 #undef BHW_LAUNCH_TILE
     return finish(hipSuccess);
 }
