@@ -753,19 +753,14 @@ __device__ __forceinline__ void tile_harmonic(const BhwCordicCfg &cfg, const int
                                               int32_t (&sv)[4])
 {
     int32_t p0, p1, p2, p3;                                // cosine term in quadrant 0..3: c, -s, -c, s
-    if constexpr (FAST && MODE == 1) {
-        const int32_t m0 = __mulhi(a, cs.x), m1 = __mulhi(a, ~cs.y), m2 = __mulhi(a, ~cs.x), m3 = __mulhi(a, cs.y);
-        p0 = (K & 1) ? -m0 : m0;
-        p1 = (K & 1) ? -m1 : m1;
-        p2 = (K & 1) ? -m2 : m2;
-        p3 = (K & 1) ? -m3 : m3;
-    } else if constexpr (FAST && MODE == 0) {
-        const int32_t mc = __mulhi(a, cs.x), ms = __mulhi(a, cs.y);
-        const int32_t uc = mc + (((uint32_t)a * (uint32_t)cs.x) != 0u), us = ms + (((uint32_t)a * (uint32_t)cs.y) != 0u);
-        p0 = (K & 1) ? -mc : mc;
-        p1 = (K & 1) ? us : -us;
-        p2 = (K & 1) ? uc : -uc;
-        p3 = (K & 1) ? -ms : ms;
+    if constexpr (FAST && MODE != 2) {
+        // four one-instruction products with the quadrant's own operand (-v or ~v); the harmonic's sign (-1)^K is NOT applied
+        // here: all four candidates carry it alike, so tile_accumulate<K, OFF, true> subtracts instead of adding for odd K
+        const int32_t nc = MODE == 1 ? ~cs.x : -cs.x, ns = MODE == 1 ? ~cs.y : -cs.y;
+        p0 = __mulhi(a, cs.x);
+        p1 = __mulhi(a, ns);
+        p2 = __mulhi(a, nc);
+        p3 = __mulhi(a, cs.y);
     } else if constexpr (MODE == 2) {
         const int32_t nc = cfg.ones_neg ? ~cs.x : -cs.x;
         const int32_t ns = cfg.ones_neg ? ~cs.y : -cs.y;
@@ -830,15 +825,23 @@ __host__ __device__ constexpr int ring_qbits(int K, int h) { return ring_quadran
 __host__ __device__ constexpr int ring_qbase(int K, int h) { return ring_qbits(K, h) == 2 ? 0 : (ring_quadrant_first(K, h) & 3); }
 
 // image j of a lane sits K*j quadrants after image 0; OFF = extra quadrants of this half-period image (even K: K/2)
-template <int K, int OFF>
+// UNSIGNED: the candidates come without the harmonic's sign (tile_harmonic FAST): odd harmonics are subtracted
+template <int K, int OFF, bool UNSIGNED = false>
 __device__ __forceinline__ void tile_accumulate(const int32_t (&sv)[4], int32_t (&acc)[4])
 {
-    acc[0] += sv[OFF & 3];
-    acc[1] += sv[(K + OFF) & 3];
-    acc[2] += sv[(2 * K + OFF) & 3];
-    acc[3] += sv[(3 * K + OFF) & 3];
+    if constexpr (UNSIGNED && (K & 1)) {
+        acc[0] -= sv[OFF & 3];
+        acc[1] -= sv[(K + OFF) & 3];
+        acc[2] -= sv[(2 * K + OFF) & 3];
+        acc[3] -= sv[(3 * K + OFF) & 3];
+    } else {
+        acc[0] += sv[OFF & 3];
+        acc[1] += sv[(K + OFF) & 3];
+        acc[2] += sv[(2 * K + OFF) & 3];
+        acc[3] += sv[(3 * K + OFF) & 3];
+    }
 }
-template <int K, int OFF>
+template <int K, int OFF, bool UNSIGNED = false>
 __device__ __forceinline__ void tile_accumulate(const int32_t (&sv)[4], Sum32 (&acc)[4])
 {
 #pragma unroll
@@ -970,13 +973,13 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
             /* only quadrant bits 0,1 of theta >> lq are used */                                         \
             const int32_t aK = FAST ? (int32_t)((uint32_t)win.aa[K] << (34u - W)) : win.aa[K];          \
             tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0), FAST>(cfg, aK, W, cs[b][0], ((uint32_t)K * rr[b]) >> lq_v, sv); \
-            tile_accumulate<K, 0>(sv, acc[b][0]);                                                        \
+            tile_accumulate<K, 0, FAST>(sv, acc[b][0]);                                                        \
             if constexpr (NG == 2) {                                                                     \
                 tile_harmonic<K, MODE, ring_qbase(K, 1), ring_qbits(K, 1), FAST>(cfg, aK, W, cs[b][NG - 1], ((uint32_t)K * (rr[b] + H)) >> lq_v, sv); \
-                tile_accumulate<K, 0>(sv, acc[b][1]);                                                    \
+                tile_accumulate<K, 0, FAST>(sv, acc[b][1]);                                                    \
             } else {                                                                                     \
                 /* even K: the second half-period image reads the same entry K/2 quadrants further on */ \
-                tile_accumulate<K, K / 2>(sv, acc[b][1]);                                                \
+                tile_accumulate<K, K / 2, FAST>(sv, acc[b][1]);                                                \
             }                                                                                            \
         }                                                                                                \
     }
