@@ -99,20 +99,15 @@ __device__ __forceinline__ uint32_t tab_index(uint32_t u, uint32_t log2_entries,
 //   7..9   "residual": between two exact records 2^d entries apart the curve deviates from the straight line through them by
 //          the CORDIC's own rounding noise (a few LSB: <= 32 rotations of < 1 LSB each, in x and in the residual angle) plus
 //          < 1 LSB of curvature (d is chosen for that, bhwk_resid_dlog).  Two bytes per entry = that deviation for c and s;
-//          int4 records {c, s, dc << 14, ds << 14} at cfg.tab_coarse (16 bytes per 2^d entries).  Build and combine evaluate the same
-//          integer predictor  rec.c + ((rec.dc * (t mod 2^d)) >> d)  (tab_predict),  so the reconstruction is exact as long as the deviation
+//          int4 records {c, s, dc, ds} at cfg.tab_coarse (16 bytes per 2^d entries).  Build and combine evaluate the same
+//          integer predictor  rec.c + ((rec.dc * (t mod 2^d)) >> d),  so the reconstruction is exact as long as the deviation
 //          fits int8 (tests/test_oracle.py::test_residual_format_margin measures <= 40 over every model and width).
 // The combine pass is bound by table + output traffic as much as by arithmetic, and these cut the table's share to 1/2 and 1/4.
 constexpr uint32_t kPackLog = 6;
 
-// Residual format predictor: rec = {c, s, dc << 14, ds << 14} of the cell, f = entry index inside the cell (< 2^d).
-//   prediction = c + floor(dc * f / 2^d) = c + mulhi(dc << 14, f << (18 - d))        (|dc|, |ds| < 2^17, so dc << 14 fits int32)
-// -- one v_mul_hi_i32 per component; the slopes are stored pre-shifted so that neither side shifts them.
-constexpr uint32_t kSlopeShift = 14;
 __device__ __forceinline__ int2 tab_predict(const int4 rec, uint32_t f, uint32_t d)
 {
-    const int32_t fs = (int32_t)(f << (32u - kSlopeShift - d));
-    return make_int2(rec.x + __mulhi(rec.z, fs), rec.y + __mulhi(rec.w, fs));
+    return make_int2(rec.x + (__mul24(rec.z, (int32_t)f) >> d), rec.y + (__mul24(rec.w, (int32_t)f) >> d));   // |dc|, |ds| < 2^17, f < 2^9
 }
 
 // v representable as a two's-complement field of `bits` bits
@@ -160,10 +155,9 @@ __device__ __forceinline__ int2 tab_fetch_k(const BhwCordicCfg &cfg, const void 
 {
     if constexpr (FMT != 2) return tab_fetch<FMT>(cfg, table, u, idx);
     else {
-        // the two deviation bytes as two sign-extending byte loads (same line; the vector-memory path has slack, the VALU not)
-        const int32_t ec = ld_off<int8_t>(table, idx << 1), es = ld_off<int8_t>(table, (idx << 1) + 1u);
+        const uint32_t e = ld_off<uint16_t>(table, idx << 1);
         const int2 p = tab_predict(ld_off<int4>(cfg.tab_coarse, (u >> rk.d) << 4), u & rk.fmask, rk.d);
-        return make_int2(p.x + ec, p.y + es);
+        return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
     }
 }
 
@@ -197,9 +191,9 @@ __device__ __forceinline__ int2 tab_load_class(const BhwCordicCfg &cfg, const vo
 {
     if constexpr (FMT == 2) {                                    // 2 bytes per entry
         const uint32_t boff = ((u >> (cls & 31u)) | cls) & ~1u;
-        const int32_t ec = ld_off<int8_t>(table, boff), es = ld_off<int8_t>(table, boff + 1u);
+        const uint32_t e = ld_off<uint16_t>(table, boff);
         const int2 p = tab_predict(ld_off<int4>(cfg.tab_coarse, (u >> rk.d) << 4), u & rk.fmask, rk.d);
-        return make_int2(p.x + ec, p.y + es);
+        return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
     } else if constexpr (FMT == 1) {                             // 4 bytes per entry
         const uint32_t boff = ((u << (cls & 31u)) | cls) & ~3u;
         const uint32_t e = ld_off<uint32_t>(table, boff);
@@ -475,10 +469,9 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
 
     auto record_of = [&](uint32_t cell) -> int4 {                  // cell in [cell_lo, cell_lo + n_cell)
         const uint32_t t = cell - cell_lo;
-        if (cell + 1u < cells_total)
-            return make_int4(hc[t], hs[t], (int32_t)((uint32_t)(hc[t + 1] - hc[t]) << kSlopeShift), (int32_t)((uint32_t)(hs[t + 1] - hs[t]) << kSlopeShift));
+        if (cell + 1u < cells_total) return make_int4(hc[t], hs[t], hc[t + 1] - hc[t], hs[t + 1] - hs[t]);
         const uint32_t tp = t ? t - 1u : n_cell + 1u;                // last cell of the table: slope of the cell before it
-        return make_int4(hc[t], hs[t], (int32_t)((uint32_t)(hc[t] - hc[tp]) << kSlopeShift), (int32_t)((uint32_t)(hs[t] - hs[tp]) << kSlopeShift));
+        return make_int4(hc[t], hs[t], hc[t] - hc[tp], hs[t] - hs[tp]);
     };
     auto record = [&](uint32_t cell) -> int4 {                     // the same for a wave-uniform cell: scalar control flow
         return record_of(__builtin_amdgcn_readfirstlane(cell));
