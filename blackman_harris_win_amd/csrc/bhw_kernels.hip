@@ -1063,6 +1063,7 @@ struct BhwFoldPlan {
     int64_t  x0;
     uint32_t n_iter, z_shr, z_shl, out_shr;
     uint32_t n_runs, phi_width, dat_width, ones_neg;
+    uint32_t fast_mul, pad0;                 // 1: every harmonic weight below 2^(W-3): one-instruction products (tile_harmonic FAST)
     uint32_t r0[kFoldRunsMax];               // first ring index of each run
     uint32_t r_end[kFoldRunsMax];            // one past its last
     uint32_t wg_first[kFoldRunsMax + 1];     // first workgroup of each run; [n_runs] = grid size
@@ -1180,6 +1181,7 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win, BhwFo
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t r = wg_r0 + threadIdx.x;
     const uint32_t lutv = plan.lut[threadIdx.x & 31u];                    // lane k (and k + 32) holds lut[k]
+    const bool fast = MODE != 2 && plan.fast_mul != 0u;
     acc_t acc[2][4];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -1235,22 +1237,38 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win, BhwFo
         chain_from(x, y, z, k0, n_iter, lutv);
         return make_int2((int32_t)(x >> out_shr), (int32_t)(y >> out_shr));
     };
+#define BHW_FD_TERM(K, HH, CS, ACC, OFF)                                                                 \
+    if (fast) {                                                           /* scalar branch */        \
+        tile_harmonic<K, MODE, ring_qbase(K, HH), ring_qbits(K, HH), MODE != 2>(cfg, (int32_t)((uint32_t)win.aa[K] << (34u - W)), W, CS, \
+                                                                                ((uint32_t)K * (r + (uint32_t)HH * H)) >> lq, sv); \
+        tile_accumulate<K, OFF, MODE != 2>(sv, ACC);                                                 \
+    } else {                                                                                         \
+        tile_harmonic<K, MODE, ring_qbase(K, HH), ring_qbits(K, HH)>(cfg, win.aa[K], W, CS, ((uint32_t)K * (r + (uint32_t)HH * H)) >> lq, sv); \
+        tile_accumulate<K, OFF>(sv, ACC);                                                            \
+    }
 #define BHW_FD_HARMONIC(K)                                                                           \
     if constexpr (NTERMS > K) {                                                                      \
         constexpr uint32_t slot = ((K - 1) / 2) * 3 + ((K & 1) ? 0 : 2);                             \
         int32_t sv[4];                                                                               \
         const int2 cs0 = chain(slot, K, 0u);                                                         \
-        tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0)>(cfg, win.aa[K], W, cs0, ((uint32_t)K * r) >> lq, sv); \
-        tile_accumulate<K, 0>(sv, acc[0]);                                                           \
         if constexpr ((K & 1) != 0) {                                                                \
+            BHW_FD_TERM(K, 0, cs0, acc[0], 0)                                                        \
             const int2 cs1 = chain(slot + 1u, K, 1u);                                                \
-            tile_harmonic<K, MODE, ring_qbase(K, 1), ring_qbits(K, 1)>(cfg, win.aa[K], W, cs1, ((uint32_t)K * (r + H)) >> lq, sv); \
-            tile_accumulate<K, 0>(sv, acc[1]);                                                       \
+            BHW_FD_TERM(K, 1, cs1, acc[1], 0)                                                        \
         } else {                                                                                     \
-            tile_accumulate<K, K / 2>(sv, acc[1]);                                                   \
+            if (fast) {                                                                              \
+                tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0), MODE != 2>(cfg, (int32_t)((uint32_t)win.aa[K] << (34u - W)), W, cs0, ((uint32_t)K * r) >> lq, sv); \
+                tile_accumulate<K, 0, MODE != 2>(sv, acc[0]);                                        \
+                tile_accumulate<K, K / 2, MODE != 2>(sv, acc[1]);                                    \
+            } else {                                                                                 \
+                tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0)>(cfg, win.aa[K], W, cs0, ((uint32_t)K * r) >> lq, sv); \
+                tile_accumulate<K, 0>(sv, acc[0]);                                                   \
+                tile_accumulate<K, K / 2>(sv, acc[1]);                                               \
+            }                                                                                        \
         }                                                                                            \
     }
     BHW_FD_HARMONIC(1) BHW_FD_HARMONIC(2) BHW_FD_HARMONIC(3) BHW_FD_HARMONIC(4) BHW_FD_HARMONIC(5) BHW_FD_HARMONIC(6)
+#undef BHW_FD_TERM
 #undef BHW_FD_HARMONIC
     if (r >= r_end) return;
 #pragma unroll
@@ -2283,6 +2301,11 @@ int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg 
     plan.phi_width = c.phi_width;
     plan.dat_width = c.dat_width;
     plan.ones_neg = c.ones_neg;
+    plan.fast_mul = (w.combine == BHW_COMBINE_HLS && c.dat_width >= 3) ? 1u : 0u;
+    for (uint32_t k = 1; k < w.n_terms && plan.fast_mul; ++k) {
+        const int64_t lim = (int64_t)1 << (c.dat_width - 3);
+        if ((int64_t)w.aa[k] >= lim || (int64_t)w.aa[k] < -lim) plan.fast_mul = 0u;
+    }
     uint64_t total = 0;
     for (uint32_t i = 0; i < n_runs; ++i) total += runs[i].r_end - runs[i].r0;
     // short launches: one wave per workgroup spreads the few waves over more CUs
