@@ -74,15 +74,45 @@ def build_library(force=False, verbose=False):
     quad = subprocess.run(["gcc", "-print-file-name=libquadmath.so"], stdout=subprocess.PIPE, text=True).stdout.strip()
     extra = os.environ.get("BHW_EXTRA_FLAGS", "").split()
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function"] + extra + ["-x", "hip",
+           "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage"] + extra + ["-x", "hip",
            os.path.join(CSRC, "bhw_api.cpp"), os.path.join(CSRC, "bhw_kernels.hip"),
            "-x", "none", rom_o, quad, "-Wl,-rpath," + os.path.dirname(os.path.realpath(quad)),
            "-o", LIB]
     out = _run(cmd)
+    _write_resources(out)
     _write_stamp(LIB, digest)
     if verbose and out:
-        print(out)
+        print("\n".join(ln for ln in out.splitlines() if "kernel-resource-usage" not in ln and not ln.lstrip().startswith(("|", "^"))
+                        and "__global__" not in ln))
     return LIB
+
+
+RESOURCES = os.path.join(HERE, "kernel_resources.json")
+
+
+def _write_resources(compiler_output):
+    """Per-kernel register / scratch / occupancy figures as the compiler reports them (-Rpass-analysis=kernel-resource-usage),
+    kept next to the library (built artefact): tests assert that the headline kernels have no scratch."""
+    import json
+    import re
+    res, cur = {}, None
+    for ln in compiler_output.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", ln)
+        if m:
+            cur = res.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+(TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|SGPRs Spill|VGPRs Spill|"
+                      r"LDS Size \[bytes/block\]): (\d+)", ln)
+        if m and cur is not None:
+            cur[m.group(1).split(" [")[0]] = int(m.group(2))
+    try:
+        names = list(res)
+        dem = subprocess.run(["c++filt"] + names, stdout=subprocess.PIPE, text=True).stdout.splitlines()
+        res = {re.sub(r"^void \(anonymous namespace\)::", "", d).split("(")[0]: res[n] for n, d in zip(names, dem)}
+    except OSError:
+        pass
+    with open(RESOURCES, "w") as f:
+        json.dump(res, f, indent=0, sort_keys=True)
 
 
 def oracle_stale():

@@ -143,3 +143,22 @@ def test_shard_range_partitions():
             assert cover[0][0] == 0 and sum(c for _, c in cover) == total
             for (a, ca), (b, _) in zip(cover, cover[1:]):
                 assert a + ca == b
+
+
+def test_headline_kernels_have_no_scratch():
+    """Register allocation of the kernels on the benchmarked path, as the compiler reports it at build time
+    (blackman_harris_win_amd/kernel_resources.json, -Rpass-analysis=kernel-resource-usage): no scratch, no VGPR spills, and the
+    tile kernel still fits two 960-thread workgroups per CU (64 VGPRs)."""
+    import json
+    from blackman_harris_win_amd import _build
+    if not os.path.exists(_build.RESOURCES):
+        _build.build_library(force=True)
+    with open(_build.RESOURCES) as f:
+        res = json.load(f)
+    headline = ["k_table_build_shared<32, 2>", "k_table_combine_tile<15, 0, 2, true>", "k_table_combine_tile<15, 1, 2, true>",
+                "k_table_combine_tile<15, 0, 2, false>", "k_fold_direct<7, 0, false>", "k_fold_direct<4, 0, true>", "k_fold_split<4, 0>",
+                "k_runlength_window<7, 1, true>"]
+    for name in headline:
+        assert name in res, name
+        assert res[name]["ScratchSize"] == 0 and res[name]["VGPRs Spill"] == 0, (name, res[name])
+    assert res["k_table_combine_tile<15, 0, 2, true>"]["VGPRs"] <= 64
