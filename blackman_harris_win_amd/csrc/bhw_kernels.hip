@@ -130,6 +130,9 @@ __device__ __forceinline__ T ld_off(const void *__restrict__ base, uint32_t byte
 // Residual format: cell size and in-cell mask as the caller holds them.  On gfx950 a VOP2 instruction with an SGPR operand
 // issues in ~4.1 cycles against ~2.5 with VGPR / inline-constant operands (profiles/r02_ubench_gfx950.txt), so the tile
 // kernel, which shifts and masks by these per gather, keeps them in VGPRs; everyone else passes the scalars.
+#ifndef BHW_TILE_DBG
+#define BHW_TILE_DBG 0      // timing experiments only (tools/ab_inproc.py with AB_NOCHECK): 1 no record loads, 2 no residual loads, 4 no stores
+#endif
 struct ResidK {
     uint32_t d;       // log2 of the cell size
     uint32_t fmask;   // 2^d - 1
@@ -150,13 +153,33 @@ __device__ __forceinline__ int2 tab_fetch(const BhwCordicCfg &cfg, const void *_
     return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
 }
 
-template <int FMT>
-__device__ __forceinline__ int2 tab_fetch_k(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t idx, const ResidK &rk)
+// Record of u's cell: from global memory, or (LDS) from the copy the wave staged in shared memory -- `lrec` + `bias` is the
+// byte address of the record of cell 0 as the staged window sees it (tile kernel).
+template <bool LDS>
+__device__ __forceinline__ int4 resid_record(const BhwCordicCfg &cfg, uint32_t u, const ResidK &rk, const char *lrec, uint32_t bias)
+{
+#if BHW_TILE_DBG & 1
+    return make_int4((int32_t)u, (int32_t)~u, 3, 5);
+#else
+    if constexpr (LDS) return *reinterpret_cast<const int4 *>(lrec + (((u >> rk.d) << 4) + bias));
+    else return ld_off<int4>(cfg.tab_coarse, (u >> rk.d) << 4);
+#endif
+}
+
+template <int FMT, bool LDS = false>
+__device__ __forceinline__ int2 tab_fetch_k(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t idx, const ResidK &rk,
+                                            const char *lrec = nullptr, uint32_t bias = 0u)
 {
     if constexpr (FMT != 2) return tab_fetch<FMT>(cfg, table, u, idx);
     else {
+#if BHW_TILE_DBG & 2
+        const uint32_t e = (idx * 0x9E37u) >> 16;
+#elif BHW_TILE_DBG & 8
+        const uint32_t e = ld_off<uint16_t>(table, (idx << 1) & 0xFFFFu);
+#else
         const uint32_t e = ld_off<uint16_t>(table, idx << 1);
-        const int2 p = tab_predict(ld_off<int4>(cfg.tab_coarse, (u >> rk.d) << 4), u & rk.fmask, rk.d);
+#endif
+        const int2 p = tab_predict(resid_record<LDS>(cfg, u, rk, lrec, bias), u & rk.fmask, rk.d);
         return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
     }
 }
@@ -186,13 +209,20 @@ __device__ __forceinline__ uint32_t split_class(uint32_t r, uint32_t log2_entrie
     return (base << LB) | amount;
 }
 
-template <int FMT>
-__device__ __forceinline__ int2 tab_load_class(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t cls, const ResidK &rk)
+template <int FMT, bool LDS = false>
+__device__ __forceinline__ int2 tab_load_class(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t cls, const ResidK &rk,
+                                               const char *lrec = nullptr, uint32_t bias = 0u)
 {
     if constexpr (FMT == 2) {                                    // 2 bytes per entry
         const uint32_t boff = ((u >> (cls & 31u)) | cls) & ~1u;
+#if BHW_TILE_DBG & 2
+        const uint32_t e = (boff * 0x9E37u) >> 16;
+#elif BHW_TILE_DBG & 8
+        const uint32_t e = ld_off<uint16_t>(table, boff & 0xFFFFu);      // same instructions, a 64 KiB window: no fabric reads
+#else
         const uint32_t e = ld_off<uint16_t>(table, boff);
-        const int2 p = tab_predict(ld_off<int4>(cfg.tab_coarse, (u >> rk.d) << 4), u & rk.fmask, rk.d);
+#endif
+        const int2 p = tab_predict(resid_record<LDS>(cfg, u, rk, lrec, bias), u & rk.fmask, rk.d);
         return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
     } else if constexpr (FMT == 1) {                             // 4 bytes per entry
         const uint32_t boff = ((u << (cls & 31u)) | cls) & ~3u;
@@ -748,9 +778,12 @@ __device__ __forceinline__ int32_t w32_final(const Sum32 &acc, uint32_t W, uint3
 // FAST (HLS rule only): every |a_k| < 2^(W-3), so a_k << (34 - W) fits int32 and  (a_k * v) >> (W-2)  is the high half of the
 // 32 x 32 product of that pre-shifted weight -- one v_mul_hi_i32 instead of v_mad_i64_i32 + v_ashrrev_i64, the low half telling
 // whether the shifted-out bits were zero.  The caller passes the pre-shifted weight as `a`.
+#ifndef BHW_TILE_ROT
+#define BHW_TILE_ROT 1      // how the quadrant rotation is written: 0 as the compiler likes it, 1 opaque bits (-1.7 %), 2/3 selects in VOP3 form via inline assembly (-1 %), 4 timing only
+#endif
 template <int K, int MODE, int QBASE = 0, int QBITS = 2, bool FAST = false>
 __device__ __forceinline__ void tile_harmonic(const BhwCordicCfg &cfg, const int32_t a, const uint32_t W, const int2 cs, const uint32_t q,
-                                              int32_t (&sv)[4])
+                                              int32_t (&sv)[4], const uint32_t qshift = 0u)
 {
     int32_t p0, p1, p2, p3;                                // cosine term in quadrant 0..3: c, -s, -c, s
     if constexpr (FAST && MODE != 2) {
@@ -796,6 +829,66 @@ __device__ __forceinline__ void tile_harmonic(const BhwCordicCfg &cfg, const int
         }
     }
     // rotate the four candidates by q so that image j (quadrant q + j*K) reads a fixed slot
+#if BHW_TILE_ROT == 4
+    sv[0] = p0; sv[1] = p1; sv[2] = p2; sv[3] = p3;                  // timing experiment only: no rotation at all (wrong results)
+#elif BHW_TILE_ROT >= 2
+    // one lane mask per quadrant bit in a scalar register pair, selects in the VOP3 form that reads it (the s_nop covers the two
+    // wait states between a vector compare and a select that reads its result as a mask)
+    auto rot1 = [](uint32_t bit, int32_t a0, int32_t a1, int32_t a2, int32_t a3, int32_t &o0, int32_t &o1, int32_t &o2, int32_t &o3) {
+        uint64_t m;
+        asm("v_cmp_ne_u32_e64 %4, 0, %5\n\ts_nop 1\n\t"
+            "v_cndmask_b32_e64 %0, %6, %7, %4\n\tv_cndmask_b32_e64 %1, %7, %8, %4\n\t"
+            "v_cndmask_b32_e64 %2, %8, %9, %4\n\tv_cndmask_b32_e64 %3, %9, %6, %4"
+            : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&s"(m) : "v"(bit), "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+    };
+    auto rot2 = [](uint32_t bit, int32_t a0, int32_t a1, int32_t a2, int32_t a3, int32_t &o0, int32_t &o1, int32_t &o2, int32_t &o3) {
+        uint64_t m;
+        asm("v_cmp_ne_u32_e64 %4, 0, %5\n\ts_nop 1\n\t"
+            "v_cndmask_b32_e64 %0, %6, %8, %4\n\tv_cndmask_b32_e64 %1, %7, %9, %4\n\t"
+            "v_cndmask_b32_e64 %2, %8, %6, %4\n\tv_cndmask_b32_e64 %3, %9, %7, %4"
+            : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&s"(m) : "v"(bit), "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+    };
+    if constexpr (QBITS == 2) {
+        static_assert(QBASE == 0, "two-bit rotation takes q as it is");
+        int32_t r0, r1, r2, r3;
+        rot1(q & (1u << qshift), p0, p1, p2, p3, r0, r1, r2, r3);
+        rot2(q & (2u << qshift), r0, r1, r2, r3, sv[0], sv[1], sv[2], sv[3]);
+    } else if constexpr (QBITS == 0) {
+        const int32_t p[4] = {p0, p1, p2, p3};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sv[i] = p[(i + QBASE) & 3];
+    } else {
+        const int32_t p[4] = {p0, p1, p2, p3};
+        rot1(((QBASE & 1) ? ~q : q) & (1u << qshift), p[QBASE & 3], p[(QBASE + 1) & 3], p[(QBASE + 2) & 3], p[(QBASE + 3) & 3], sv[0], sv[1], sv[2], sv[3]);
+    }
+#elif BHW_TILE_ROT == 1
+    // quadrant bits as opaque 0 / 1 values: one compare per bit, plain selects (left to itself the compiler turns the selects into
+    // an indexed read of the four candidates and that into a chain of three compare + select pairs per slot)
+    if constexpr (QBITS == 2) {
+        static_assert(QBASE == 0, "two-bit rotation takes q as it is");
+        uint32_t q0 = q & 1u, q1 = q & 2u;
+        asm("" : "+v"(q0), "+v"(q1));
+        const bool b0 = q0 != 0u, b1 = q1 != 0u;
+        const int32_t r0 = b0 ? p1 : p0, r1 = b0 ? p2 : p1, r2 = b0 ? p3 : p2, r3 = b0 ? p0 : p3;
+        sv[0] = b1 ? r2 : r0;
+        sv[1] = b1 ? r3 : r1;
+        sv[2] = b1 ? r0 : r2;
+        sv[3] = b1 ? r1 : r3;
+    } else if constexpr (QBITS == 0) {
+        const int32_t p[4] = {p0, p1, p2, p3};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sv[i] = p[(i + QBASE) & 3];
+    } else {
+        uint32_t q0 = (q ^ (uint32_t)QBASE) & 1u;
+        asm("" : "+v"(q0));
+        const bool b0 = q0 != 0u;
+        auto pick = [&](int i) -> int32_t { return (i & 3) == 0 ? p0 : (i & 3) == 1 ? p1 : (i & 3) == 2 ? p2 : p3; };
+        sv[0] = b0 ? pick(QBASE + 1) : pick(QBASE);
+        sv[1] = b0 ? pick(QBASE + 2) : pick(QBASE + 1);
+        sv[2] = b0 ? pick(QBASE + 3) : pick(QBASE + 2);
+        sv[3] = b0 ? pick(QBASE + 4) : pick(QBASE + 3);
+    }
+#else
     if constexpr (QBITS == 2) {
         static_assert(QBASE == 0, "two-bit rotation takes q as it is");
         const bool b0 = q & 1u, b1 = q & 2u;
@@ -815,6 +908,7 @@ __device__ __forceinline__ void tile_harmonic(const BhwCordicCfg &cfg, const int
             for (int i = 0; i < 4; ++i) sv[i] = b0 ? p[(i + QBASE + 1) & 3] : p[(i + QBASE) & 3];
         }
     }
+#endif
 }
 
 // Quadrants harmonic K can be in for a ring lane r in [0, N/8) (image h: r + h * N/8): theta / (N/4) lies in [K*h/2, K*h/2 + K/2).
@@ -823,6 +917,48 @@ __host__ __device__ constexpr int ring_quadrant_first(int K, int h) { return (K 
 __host__ __device__ constexpr int ring_quadrant_count(int K, int h) { return ((K * h + K - 1) >> 1) - ((K * h) >> 1) + 1; }
 __host__ __device__ constexpr int ring_qbits(int K, int h) { return ring_quadrant_count(K, h) == 1 ? 0 : ring_quadrant_count(K, h) == 2 ? 1 : 2; }
 __host__ __device__ constexpr int ring_qbase(int K, int h) { return ring_qbits(K, h) == 2 ? 0 : (ring_quadrant_first(K, h) & 3); }
+
+// Wave-uniform quadrant (tile kernel, tiles in which no run crosses a multiple of a quarter turn): the rotation of the four
+// candidates becomes a scalar branch to the accumulate code of that quadrant instead of 4 - 8 vector selects per gather:
+//   acc[j] -/+= sv[(j*K + OFF + q) & 3],  q a scalar.
+// One inline-assembly statement per gather holds the compare, the branches and the adds of every case: written as C++ control
+// flow the compiler sinks the adds below the join and leaves a register move per slot in the cases (the selects again).
+// QBITS as in tile_harmonic: 1 = q is QBASE or QBASE + 1 (two cases), 2 = any quadrant (four cases).
+template <int K, int OFF, int QBASE, int QBITS>
+__device__ __forceinline__ void tile_accumulate_uniform(uint32_t q, const int32_t (&sv)[4], int32_t (&acc)[4])
+{
+    auto S = [&](int j, int Q) -> int32_t { return sv[(j * K + OFF + Q) & 3]; };
+    if constexpr (QBITS == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = (K & 1) ? acc[j] - S(j, QBASE) : acc[j] + S(j, QBASE);
+    } else if constexpr (QBITS == 1) {
+#define BHW_UNI2(OP)                                                                                                   \
+        asm("s_cmp_eq_u32 %12, %13\n\ts_cbranch_scc0 1f\n\t"                                                          \
+            OP " %0, %0, %4\n\t" OP " %1, %1, %5\n\t" OP " %2, %2, %6\n\t" OP " %3, %3, %7\n\ts_branch 2f\n1:\n\t"      \
+            OP " %0, %0, %8\n\t" OP " %1, %1, %9\n\t" OP " %2, %2, %10\n\t" OP " %3, %3, %11\n2:"                        \
+            : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])                                                   \
+            : "v"(S(0, QBASE)), "v"(S(1, QBASE)), "v"(S(2, QBASE)), "v"(S(3, QBASE)),                                  \
+              "v"(S(0, QBASE + 1)), "v"(S(1, QBASE + 1)), "v"(S(2, QBASE + 1)), "v"(S(3, QBASE + 1)), "s"(q), "n"(QBASE) : "scc")
+        if constexpr (K & 1) BHW_UNI2("v_sub_u32"); else BHW_UNI2("v_add_u32");
+#undef BHW_UNI2
+    } else {
+#define BHW_UNI4(OP)                                                                                                   \
+        asm("s_cmp_lt_u32 %20, 2\n\ts_cbranch_scc0 2f\n\ts_cmp_eq_u32 %20, 0\n\ts_cbranch_scc0 1f\n\t"                   \
+            OP " %0, %0, %4\n\t" OP " %1, %1, %5\n\t" OP " %2, %2, %6\n\t" OP " %3, %3, %7\n\ts_branch 4f\n1:\n\t"      \
+            OP " %0, %0, %8\n\t" OP " %1, %1, %9\n\t" OP " %2, %2, %10\n\t" OP " %3, %3, %11\n\ts_branch 4f\n2:\n\t"   \
+            "s_cmp_eq_u32 %20, 2\n\ts_cbranch_scc0 3f\n\t"                                                             \
+            OP " %0, %0, %12\n\t" OP " %1, %1, %13\n\t" OP " %2, %2, %14\n\t" OP " %3, %3, %15\n\ts_branch 4f\n3:\n\t" \
+            OP " %0, %0, %16\n\t" OP " %1, %1, %17\n\t" OP " %2, %2, %18\n\t" OP " %3, %3, %19\n4:"                      \
+            : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])                                                   \
+            : "v"(S(0, 0)), "v"(S(1, 0)), "v"(S(2, 0)), "v"(S(3, 0)), "v"(S(0, 1)), "v"(S(1, 1)), "v"(S(2, 1)), "v"(S(3, 1)), \
+              "v"(S(0, 2)), "v"(S(1, 2)), "v"(S(2, 2)), "v"(S(3, 2)), "v"(S(0, 3)), "v"(S(1, 3)), "v"(S(2, 3)), "v"(S(3, 3)), \
+              "s"(q) : "scc")
+        if constexpr (K & 1) BHW_UNI4("v_sub_u32"); else BHW_UNI4("v_add_u32");
+#undef BHW_UNI4
+    }
+}
+template <int K, int OFF, int QBASE, int QBITS>
+__device__ __forceinline__ void tile_accumulate_uniform(uint32_t, const int32_t (&)[4], Sum32 (&)[4]) {}   // VHDL rule: never taken (see the call)
 
 // image j of a lane sits K*j quadrants after image 0; OFF = extra quadrants of this half-period image (even K: K/2)
 // UNSIGNED: the candidates come without the harmonic's sign (tile_harmonic FAST): odd harmonics are subtracted
@@ -892,6 +1028,42 @@ __global__ __launch_bounds__(kBlock) void k_table_combine_fold_t(BhwCordicCfg cf
     }
 }
 
+// Residual-format records through LDS (BHW_TILE_LDSREC).  On gfx950 a vector load whose lanes do not read consecutive elements
+// costs the CU's address path ~16 cycles per wave-instruction whatever its width, a unit-stride one ~4.7
+// (profiles/r02_ubench_vmem.txt), and the tile kernel issues 54 such loads per thread: the address path, not the vector ALU, is
+// what bounds it.  The records (16 bytes per cell of 2^d >= 128 entries) of the cells a wave's three runs touch are few -- for
+// harmonic K a run of 192 lanes spans K * 191 + 1 entries -- so every wave copies them into shared memory once (three load
+// instructions) and its 27 gathers read them with ds_read_b128 instead.  Set (K, g) of run b holds rec_slots(K) consecutive cells
+// from the cell of the run's first lane; tiles in which a run wraps around the ring or a harmonic's entries wrap around the table
+// (a few dozen of the 14 564) take the global loads.
+#ifndef BHW_TILE_LDSREC
+#define BHW_TILE_LDSREC 1
+#endif
+#ifndef BHW_TILE_NTSTORE
+#define BHW_TILE_NTSTORE 0     // nontemporal coefficient stores: +7 % time (0.1497 -> 0.1600 ms), measured again in round 2
+#endif
+#ifndef BHW_TILE_UNIQ
+#define BHW_TILE_UNIQ 1       // scalar quadrants in the tiles that take the LDS path (quad_switch)
+#endif
+constexpr int kRecSets = 9;                                      // (K, g): (1,0) (1,1) (2) (3,0) (3,1) (4) (5,0) (5,1) (6)
+__host__ __device__ constexpr int rec_set_K(int si) { return si < 2 ? 1 : si == 2 ? 2 : si < 5 ? 3 : si == 5 ? 4 : si < 8 ? 5 : 6; }
+__host__ __device__ constexpr int rec_set_g(int si) { return (si == 1 || si == 4 || si == 7) ? 1 : 0; }
+__host__ __device__ constexpr int rec_set_index(int K, int g) { return K == 1 ? g : K == 2 ? 2 : K == 3 ? 3 + g : K == 4 ? 5 : K == 5 ? 6 + g : 8; }
+__host__ __device__ constexpr int rec_slots(int K) { return ((K * (kTileLanes - 1) + 127) >> 7) + 1; }   // cells of >= 128 entries
+__host__ __device__ constexpr int rec_set_base(int si) { int s = 0; for (int i = 0; i < si; ++i) s += rec_slots(rec_set_K(i)); return s; }
+constexpr int kRecPerRun = rec_set_base(kRecSets);               // 57 for 192-lane runs
+static_assert(kRecPerRun <= 64, "slot -> (K, g, j) table");
+struct RecMeta { uint8_t v[64]; };
+constexpr RecMeta make_rec_meta()
+{
+    RecMeta m{};
+    int s = 0;
+    for (int si = 0; si < kRecSets; ++si)
+        for (int j = 0; j < rec_slots(rec_set_K(si)); ++j) m.v[s++] = (uint8_t)(rec_set_K(si) | (rec_set_g(si) << 3) | (j << 4));
+    return m;
+}
+__device__ const RecMeta kRecMeta = make_rec_meta();
+
 // Lane r in [0, E/2) owns the eight coefficients n = r + h*E/2 + j*E (h = 0,1; j = 0..3).  For even k the
 // two h-images share one gather (k*E/2 is a whole number of quadrants); for odd k the second image reads
 // entry t + E/2, another dense span of the same tile.
@@ -925,11 +1097,57 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
     }
     const uint32_t part = __builtin_amdgcn_readfirstlane(threadIdx.x / kLanes);   // wave-uniform: kLanes is a multiple of 64
     const uint32_t lane_in_part = threadIdx.x % kLanes;
-    uint32_t rr[NR];
+    constexpr bool kLdsRec = BHW_TILE_LDSREC && FMT == 2 && NB >= 15 && kLanes == kTileLanes;
+    uint32_t rec_meta = 0;                                           // slot -> (K, g, j) of the record staging below, fetched first
+    if constexpr (kLdsRec) rec_meta = kRecMeta.v[threadIdx.x & 63u];
+    uint32_t rr[NR], starts[NR];
 #pragma unroll
     for (int b = 0; b < NR; ++b) {
         const uint32_t start = ((tile_of_block + tp.tile0) * kLanes + tp.offs[part * NR + b]) & hmask;   // scalar; offs padded with copies of the last run
+        starts[b] = start;
         rr[b] = (start + (lane_in_part + kLanes - (start & 63u)) % kLanes) & hmask;
+    }
+    // records of the cells this wave's runs touch, staged in shared memory (see BHW_TILE_LDSREC above)
+    constexpr int kWavesWg = kTileThreads / 64;
+    __shared__ int4 rec_s[kLdsRec ? kWavesWg * NR * kRecPerRun : 1];
+    uint32_t rbias[kRecSets][NR];                                    // scalar: byte offset of "cell 0" of set si, run b in rec_s
+    uint32_t qpack[NR];                                              // scalar: quadrant of set si, run b in bits 2 si, 2 si + 1
+    bool wraps = false;
+    if constexpr (kLdsRec) {
+        const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const uint32_t d = cfg.tab_dlog;
+#pragma unroll
+        for (int b = 0; b < NR; ++b) {
+            wraps |= starts[b] + (uint32_t)kLanes > H;
+            qpack[b] = 0u;
+#pragma unroll
+            for (int si = 0; si < kRecSets; ++si) {
+                const uint32_t K = rec_set_K(si);
+                const uint32_t th0 = K * (starts[b] + (uint32_t)rec_set_g(si) * H);
+                const uint32_t u0 = th0 & emask;
+                qpack[b] |= ((th0 >> lq) & 3u) << (2 * si);
+                wraps |= u0 + K * (uint32_t)(kLanes - 1) > emask;
+                rbias[si][b] = (((wave * NR + b) * kRecPerRun + (uint32_t)rec_set_base(si)) << 4) - ((u0 >> d) << 4);
+            }
+        }
+        if (!wraps) {
+            // lane s < kRecPerRun copies slot s of each of the wave's NR runs: the NR loads are in flight together
+            const uint32_t s = threadIdx.x & 63u;
+            if (s < (uint32_t)kRecPerRun) {
+                const uint32_t meta = rec_meta;
+                int4 rec[NR];
+#pragma unroll
+                for (int b = 0; b < NR; ++b) {
+                    const uint32_t u0 = ((meta & 7u) * (starts[b] + ((meta >> 3) & 1u) * H)) & emask;
+                    const uint32_t cell = ((u0 >> d) + (meta >> 4)) & ((E >> d) - 1u);
+                    rec[b] = ld_off<int4>(cfg.tab_coarse, cell << 4);
+                }
+#pragma unroll
+                for (int b = 0; b < NR; ++b) rec_s[(wave * NR + b) * kRecPerRun + s] = rec[b];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                         // the wave's own LDS writes are ordered before its reads
+        }
     }
 #ifndef BHW_TILE_VGPR_CONSTS
 #define BHW_TILE_VGPR_CONSTS 0      // measured: 1 is 1 % slower (profiles/r02_ab_tile_kernel_steps.txt) -- register pressure outweighs the cheaper operands
@@ -953,6 +1171,9 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
                 else acc[b][h][j] = win.aa[0];
             }
 
+    auto harmonics = [&](auto lds_tag) {
+    constexpr bool LDS = decltype(lds_tag)::value;
+    const char *lrec = reinterpret_cast<const char *>(rec_s);
 #define BHW_TILE_HARMONIC(K)                                                                             \
     if (win.n_terms > K) {                                                                               \
         constexpr int NG = (K & 1) ? 2 : 1;                                                              \
@@ -961,10 +1182,11 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
         _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
             _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                             \
                 const uint32_t theta = (uint32_t)K * (rr[b] + (uint32_t)g * H);                          \
-                if constexpr (NB > 1 && (K & 1)) cs[b][g] = tab_load_class<FMT>(cfg, table, theta & emask_v, cls[b], rk); \
+                const uint32_t bias = rbias[rec_set_index(K, g)][b];                                     \
+                if constexpr (NB > 1 && (K & 1)) cs[b][g] = tab_load_class<FMT, LDS>(cfg, table, theta & emask_v, cls[b], rk, lrec, bias); \
                 else if constexpr (NB > 1) {                                                             \
                     const uint32_t u = theta & emask_v;                                                  \
-                    cs[b][g] = tab_fetch_k<FMT>(cfg, table, u, tab_index<KC, 1>(u, lq, 1u), rk);         \
+                    cs[b][g] = tab_fetch_k<FMT, LDS>(cfg, table, u, tab_index<KC, 1>(u, lq, 1u), rk, lrec, bias); \
                 } else cs[b][g] = tab_load<KC, FMT, -1>(cfg, table, (theta & emask) >> cfg.z_shr, lq - cfg.z_shr); \
             }                                                                                            \
         }                                                                                                \
@@ -972,10 +1194,25 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
             int32_t sv[4];                                                                               \
             /* only quadrant bits 0,1 of theta >> lq are used */                                         \
             const int32_t aK = FAST ? (int32_t)((uint32_t)win.aa[K] << (34u - W)) : win.aa[K];          \
-            tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0), FAST>(cfg, aK, W, cs[b][0], ((uint32_t)K * rr[b]) >> lq_v, sv); \
+            if constexpr (LDS && BHW_TILE_UNIQ && FAST && MODE != 2) {                                   \
+                /* no run of this tile crosses a quarter turn: the quadrants are scalars (qpack) */      \
+                tile_harmonic<K, MODE, 0, 0, FAST>(cfg, aK, W, cs[b][0], 0u, sv);                        \
+                const uint32_t q0 = (qpack[b] >> (2 * rec_set_index(K, 0))) & 3u;                        \
+                tile_accumulate_uniform<K, 0, ring_qbase(K, 0), ring_qbits(K, 0)>(q0, sv, acc[b][0]);    \
+                if constexpr (NG == 1) tile_accumulate_uniform<K, K / 2, ring_qbase(K, 0), ring_qbits(K, 0)>(q0, sv, acc[b][1]); \
+                else {                                                                                   \
+                    tile_harmonic<K, MODE, 0, 0, FAST>(cfg, aK, W, cs[b][1], 0u, sv);                    \
+                    const uint32_t q1 = (qpack[b] >> (2 * rec_set_index(K, 1))) & 3u;                    \
+                    tile_accumulate_uniform<K, 0, ring_qbase(K, 1), ring_qbits(K, 1)>(q1, sv, acc[b][1]); \
+                }                                                                                        \
+                continue;                                                                                \
+            }                                                                                            \
+            if constexpr (BHW_TILE_ROT == 3) tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0), FAST>(cfg, aK, W, cs[b][0], (uint32_t)K * rr[b], sv, lq); \
+            else tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0), FAST>(cfg, aK, W, cs[b][0], ((uint32_t)K * rr[b]) >> lq_v, sv); \
             tile_accumulate<K, 0, FAST>(sv, acc[b][0]);                                                        \
             if constexpr (NG == 2) {                                                                     \
-                tile_harmonic<K, MODE, ring_qbase(K, 1), ring_qbits(K, 1), FAST>(cfg, aK, W, cs[b][NG - 1], ((uint32_t)K * (rr[b] + H)) >> lq_v, sv); \
+                if constexpr (BHW_TILE_ROT == 3) tile_harmonic<K, MODE, ring_qbase(K, 1), ring_qbits(K, 1), FAST>(cfg, aK, W, cs[b][NG - 1], (uint32_t)K * (rr[b] + H), sv, lq); \
+                else tile_harmonic<K, MODE, ring_qbase(K, 1), ring_qbits(K, 1), FAST>(cfg, aK, W, cs[b][NG - 1], ((uint32_t)K * (rr[b] + H)) >> lq_v, sv); \
                 tile_accumulate<K, 0, FAST>(sv, acc[b][1]);                                                    \
             } else {                                                                                     \
                 /* even K: the second half-period image reads the same entry K/2 quadrants further on */ \
@@ -990,6 +1227,11 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
     BHW_TILE_HARMONIC(5)
     BHW_TILE_HARMONIC(6)
 #undef BHW_TILE_HARMONIC
+    };
+    if constexpr (kLdsRec) {
+        if (wraps) harmonics(std::false_type{});                     // block-uniform
+        else harmonics(std::true_type{});
+    } else harmonics(std::false_type{});
 
     auto final_value = [&](int b, int h, int j) -> int32_t {
         if constexpr (MODE == 2) return w32_final<BHW_COMBINE_VHDL>(acc[b][h][j], W, win.n_terms);
@@ -1011,7 +1253,14 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
                         int32_t v;
                         if constexpr (MODE != 2 && decltype(full_width)::value) v = acc_value(acc[b][h][j]);   // W == 32: nothing to wrap
                         else v = final_value(b, h, j);
+#if BHW_TILE_DBG & 4
+                        if (v == 0x12345)
+#endif
+#if BHW_TILE_NTSTORE
+                        __builtin_nontemporal_store(v, reinterpret_cast<int32_t *>(reinterpret_cast<char *>(img) + (rr[b] << 2)));
+#else
                         *reinterpret_cast<int32_t *>(reinterpret_cast<char *>(img) + (rr[b] << 2)) = v;
+#endif
                     }
                 }
         };
