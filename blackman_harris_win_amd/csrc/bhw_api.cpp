@@ -375,19 +375,21 @@ int check_exec(const bhw_exec *ex)
     if (!ex) return BHW_OK;
     if (ex->struct_size != sizeof(bhw_exec) && ex->struct_size != 32u)       // 32 = the ABI-1 layout (no table_format)
         return fail(BHW_ERR_BADARG, "bhw_exec.struct_size %u", ex->struct_size);
-    if (ex->struct_size >= sizeof(bhw_exec) && (ex->table_format > BHW_TABLE_RESIDUAL || ex->reserved != 0))
+    if (ex->struct_size >= sizeof(bhw_exec) && (ex->table_format > BHW_TABLE_NIBBLE || ex->reserved != 0))
         return fail(BHW_ERR_BADARG, "bhw_exec.table_format %u / reserved %u", ex->table_format, ex->reserved);
     return BHW_OK;
 }
 
-// Table formats a tiled whole-period call may use, narrowest first (tab_dlog values: 7..9 residual, 6 delta16, 0 plain).
-// The packed build variants exist from 21 rotations on (always true at PW >= 22).
-int table_format_candidates(const BhwCordicCfg &c, bool tiled, uint32_t limit, uint32_t out[3])
+// Table formats a tiled whole-period call may use, narrowest first (tab_dlog values: 16 + d nibble, d = 7..9 residual, 6 delta16,
+// 0 plain).  The packed build variants exist from 21 rotations on (always true at PW >= 22).
+constexpr int kMaxFormats = 4;
+int table_format_candidates(const BhwCordicCfg &c, bool tiled, uint32_t limit, uint32_t out[kMaxFormats])
 {
     int n = 0;
     if (tiled && c.n_iter >= 21) {
         const uint32_t d = bhwk_resid_dlog(c);
-        if (d && (limit == BHW_TABLE_BEST || limit == BHW_TABLE_RESIDUAL)) out[n++] = d;
+        if (d && (limit == BHW_TABLE_BEST || limit == BHW_TABLE_NIBBLE)) out[n++] = 16u + d;
+        if (d && (limit == BHW_TABLE_BEST || limit == BHW_TABLE_NIBBLE || limit == BHW_TABLE_RESIDUAL)) out[n++] = d;
         if (bhwk_packed_ok(c) && limit != BHW_TABLE_PLAIN) out[n++] = 6u;
     }
     out[n++] = 0u;
@@ -400,7 +402,7 @@ int table_format_candidates(const BhwCordicCfg &c, bool tiled, uint32_t limit, u
 // [ entries | ... | records / block heads at byte offset E*4 | ... | check word in the last 8 bytes ].
 int build_table(const bhw_params *p, const BhwLaunch &l, BhwCordicCfg &c, bool tiled, uint32_t limit, void *ws)
 {
-    uint32_t cand[3];
+    uint32_t cand[kMaxFormats];
     const int n_cand = table_format_candidates(c, tiled, limit, cand);
     const uint64_t E = table_entries(c);
     for (int i = 0; i < n_cand; ++i) {
@@ -667,7 +669,7 @@ int bhw_describe_plan(const bhw_params *p, uint64_t n0, uint64_t count, const bh
     }
     const bool tiled = period && bhwk_tile_applicable(c, w);
     c.tab_split = (tiled && c.z_shr == 0) ? 1u : 0u;
-    uint32_t cand[3];
+    uint32_t cand[kMaxFormats];
     const int n_cand = table_format_candidates(c, tiled, exec_table_format(ex), cand);
     const char *state = "";
     c.tab_dlog = 0;
@@ -680,7 +682,7 @@ int bhw_describe_plan(const bhw_params *p, uint64_t n0, uint64_t count, const bh
     }
     char build[64], combine[64];
     bhwk_describe_table(c, w, tiled, build, combine, sizeof build);
-    const char *fmt = c.tab_dlog == 0 ? "plain" : c.tab_dlog == 6 ? "delta16" : "residual";
+    const char *fmt = c.tab_dlog == 0 ? "plain" : c.tab_dlog == 6 ? "delta16" : c.tab_dlog >= 16 ? "nibble" : "residual";
     snprintf(buf, len, "table[%s%s]: %s + %s%s", fmt, state, build, period ? combine : "k_table_combine",
              period && count != (1ull << p->phi_width) ? " (+ k_table_combine / k_replicate on the rest)" : "");
     return BHW_OK;
@@ -818,11 +820,11 @@ int bhw_dbg_table_combine(const bhw_params *p, int device, void *stream, const v
     return bhwk_table_combine_fold(l, c, w, (const int32_t *)ws, d_out);
 }
 
-// Builds the table of `p` in the packed format `dlog` (6 delta16, 7..9 residual) with the overflow check on, whether or not
+// Builds the table of `p` in the packed format `dlog` (6 delta16, 7..9 residual, 23..25 nibble) with the overflow check on, whether or not
 // the format would be chosen for this configuration, and returns the check word.  `ws`: bhw_workspace_bytes(TABLE) bytes.
 int bhw_dbg_check_table_format(const bhw_params *p, int device, void *stream, uint32_t dlog, void *ws, uint32_t *flag_out)
 {
-    if (validate(p) || !ws || !flag_out || dlog < 6 || dlog > 9) return BHW_ERR_BADARG;
+    if (validate(p) || !ws || !flag_out || dlog < 6 || (dlog > 9 && (dlog < 16u + 7u || dlog > 16u + 9u))) return BHW_ERR_BADARG;
     BhwCordicCfg c;
     resolve_cordic(p, c);
     if (c.z_shr != 0 || c.n_iter < 21 || c.dat_width + c.out_shr > 34 || table_entries(c) < (1ull << 12)) return BHW_ERR_UNSUPPORTED;

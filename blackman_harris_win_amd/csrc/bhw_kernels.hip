@@ -102,8 +102,15 @@ __device__ __forceinline__ uint32_t tab_index(uint32_t u, uint32_t log2_entries,
 //          int4 records {c, s, dc, ds} at cfg.tab_coarse (16 bytes per 2^d entries).  Build and combine evaluate the same
 //          integer predictor  rec.c + ((rec.dc * (t mod 2^d)) >> d),  so the reconstruction is exact as long as the deviation
 //          fits int8 (tests/test_oracle.py::test_residual_format_margin measures <= 40 over every model and width).
-// The combine pass is bound by table + output traffic as much as by arithmetic, and these cut the table's share to 1/2 and 1/4.
+//   23..25 "nibble" (16 + d): the residual format with the two deviations in 4-bit fields, one byte per entry.  The deviations
+//          of the 32-bit HLS model stay within -5 .. 6 over the whole 2^24-entry table of a 2^26-point window (measured with the
+//          oracle); like the other packed formats it is used only after the build kernel has checked every entry of the
+//          configuration (a model whose noise is wider -- the cpp model reaches 10 -- falls back to the byte fields).
+// The combine pass is bound by table + output traffic as much as by arithmetic, and these cut the table's share to 1/2 .. 1/8.
 constexpr uint32_t kPackLog = 6;
+constexpr uint32_t kNibbleFlag = 16;            // cfg.tab_dlog = kNibbleFlag + d
+__host__ __device__ constexpr uint32_t fmt_cell_log(uint32_t tab_dlog) { return tab_dlog & (kNibbleFlag - 1u); }
+__host__ __device__ constexpr int fmt_of(uint32_t tab_dlog) { return tab_dlog == 0 ? 0 : tab_dlog == kPackLog ? 1 : tab_dlog >= kNibbleFlag ? 3 : 2; }
 
 __device__ __forceinline__ int2 tab_predict(const int4 rec, uint32_t f, uint32_t d)
 {
@@ -147,9 +154,13 @@ __device__ __forceinline__ int2 tab_fetch(const BhwCordicCfg &cfg, const void *_
         const int2 base = ld_off<int2>(cfg.tab_coarse, (u >> kPackLog) << 3);
         return make_int2(base.x + (int32_t)(int16_t)(e & 0xFFFFu), base.y + ((int32_t)e >> 16));
     }
-    const uint32_t d = cfg.tab_dlog;
-    const uint32_t e = ld_off<uint16_t>(table, idx << 1);
+    const uint32_t d = fmt_cell_log(cfg.tab_dlog);
     const int2 p = tab_predict(ld_off<int4>(cfg.tab_coarse, (u >> d) << 4), u & ((1u << d) - 1u), d);
+    if (FMT == 3 || (FMT < 0 && cfg.tab_dlog >= kNibbleFlag)) {
+        const uint32_t e = ld_off<uint8_t>(table, idx);
+        return make_int2(p.x + ((int32_t)(e << 28) >> 28), p.y + ((int32_t)(e << 24) >> 28));
+    }
+    const uint32_t e = ld_off<uint16_t>(table, idx << 1);
     return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
 }
 
@@ -170,7 +181,11 @@ template <int FMT, bool LDS = false>
 __device__ __forceinline__ int2 tab_fetch_k(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t idx, const ResidK &rk,
                                             const char *lrec = nullptr, uint32_t bias = 0u)
 {
-    if constexpr (FMT != 2) return tab_fetch<FMT>(cfg, table, u, idx);
+    if constexpr (FMT == 3) {
+        const uint32_t e = ld_off<uint8_t>(table, idx);
+        const int2 p = tab_predict(resid_record<LDS>(cfg, u, rk, lrec, bias), u & rk.fmask, rk.d);
+        return make_int2(p.x + ((int32_t)(e << 28) >> 28), p.y + ((int32_t)(e << 24) >> 28));
+    } else if constexpr (FMT != 2) return tab_fetch<FMT>(cfg, table, u, idx);
     else {
 #if BHW_TILE_DBG & 2
         const uint32_t e = (idx * 0x9E37u) >> 16;
@@ -201,11 +216,11 @@ __device__ __forceinline__ int2 tab_load(const BhwCordicCfg &cfg, const void *__
 template <int FMT>
 __device__ __forceinline__ uint32_t split_class(uint32_t r, uint32_t log2_entries)
 {
-    constexpr uint32_t LB = FMT == 2 ? 1u : FMT == 1 ? 2u : 3u;
+    constexpr uint32_t LB = (FMT == 2 || FMT == 3) ? 1u : FMT == 1 ? 2u : 3u;   // FMT 3: the word of FMT 2, the offset halved at the load
     const uint32_t e = 1u << log2_entries;
     const uint32_t s = (r & 1u) ? 1u : 2u;
     const uint32_t base = (r & 1u) ? (e >> 1) : (((r >> 1) & 1u) ? (e >> 2) : 0u);
-    const uint32_t amount = FMT == 2 ? s - 1u : LB - s;          // FMT 2: right by s - 1 (0 / 1); else left by LB - s (0 .. 2)
+    const uint32_t amount = (FMT == 2 || FMT == 3) ? s - 1u : LB - s;   // FMT 2 / 3: right by s - 1 (0 / 1); else left by LB - s (0 .. 2)
     return (base << LB) | amount;
 }
 
@@ -213,7 +228,11 @@ template <int FMT, bool LDS = false>
 __device__ __forceinline__ int2 tab_load_class(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t cls, const ResidK &rk,
                                                const char *lrec = nullptr, uint32_t bias = 0u)
 {
-    if constexpr (FMT == 2) {                                    // 2 bytes per entry
+    if constexpr (FMT == 3) {                                    // 1 byte per entry: index = the 2-byte offset halved
+        const uint32_t e = ld_off<uint8_t>(table, ((u >> (cls & 31u)) | cls) >> 1);
+        const int2 p = tab_predict(resid_record<LDS>(cfg, u, rk, lrec, bias), u & rk.fmask, rk.d);
+        return make_int2(p.x + ((int32_t)(e << 28) >> 28), p.y + ((int32_t)(e << 24) >> 28));
+    } else if constexpr (FMT == 2) {                             // 2 bytes per entry
         const uint32_t boff = ((u >> (cls & 31u)) | cls) & ~1u;
 #if BHW_TILE_DBG & 2
         const uint32_t e = (boff * 0x9E37u) >> 16;
@@ -250,10 +269,16 @@ __device__ __forceinline__ void tab_store(void *__restrict__ table, uint32_t u, 
         reinterpret_cast<uint32_t *>(table)[idx] = ((uint32_t)dc & 0xFFFFu) | ((uint32_t)ds << 16);
         if ((u & ((1u << kPackLog) - 1u)) == 0u) reinterpret_cast<int2 *>(coarse)[u >> kPackLog] = make_int2(c, s);
     } else {
-        const int2 p = tab_predict(rec, u & ((1u << dlog) - 1u), dlog);
+        const uint32_t d = fmt_cell_log(dlog);
+        const int2 p = tab_predict(rec, u & ((1u << d) - 1u), d);
         const int32_t dc = c - p.x, ds = s - p.y;
-        if (check_flag && !(fits_bits(dc, 8) && fits_bits(ds, 8))) atomicOr(check_flag, 1u);
-        reinterpret_cast<uint16_t *>(table)[idx] = (uint16_t)(((uint32_t)dc & 0xFFu) | (((uint32_t)ds & 0xFFu) << 8));
+        if (FMT == 3 || (FMT < 0 && dlog >= kNibbleFlag)) {
+            if (check_flag && !(fits_bits(dc, 4) && fits_bits(ds, 4))) atomicOr(check_flag, 1u);
+            reinterpret_cast<uint8_t *>(table)[idx] = (uint8_t)(((uint32_t)dc & 0xFu) | (((uint32_t)ds & 0xFu) << 4));
+        } else {
+            if (check_flag && !(fits_bits(dc, 8) && fits_bits(ds, 8))) atomicOr(check_flag, 1u);
+            reinterpret_cast<uint16_t *>(table)[idx] = (uint16_t)(((uint32_t)dc & 0xFFu) | (((uint32_t)ds & 0xFFu) << 8));
+        }
     }
 }
 
@@ -358,7 +383,7 @@ __global__ __launch_bounds__(kBlock) void k_table_build(BhwCordicCfg cfg, uint32
     const int32_t c = (int32_t)(x >> cfg.out_shr), sn = (int32_t)(y >> cfg.out_shr);
     // a wave holds one aligned 64-entry block (the packed format needs entries >= 64, see bhwk_packed_ok)
     const int2 head = make_int2(__builtin_amdgcn_readfirstlane(c), __builtin_amdgcn_readfirstlane(sn));
-    const int4 rec = cfg.tab_dlog > kPackLog ? reinterpret_cast<const int4 *>(cfg.tab_coarse)[u >> cfg.tab_dlog] : make_int4(0, 0, 0, 0);
+    const int4 rec = cfg.tab_dlog > kPackLog ? reinterpret_cast<const int4 *>(cfg.tab_coarse)[u >> fmt_cell_log(cfg.tab_dlog)] : make_int4(0, 0, 0, 0);
     tab_store(table, u, cfg.phi_width - 2 - cfg.z_shr, cfg.tab_split, cfg.tab_dlog, const_cast<void *>(cfg.tab_coarse), c, sn, head, rec,
               cfg.tab_check);
 }
@@ -445,8 +470,8 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
     // for the table's last cell, whose end point is not an entry and which reuses the slope of the cell before it -- while
     // the first wave runs the group prefixes; cells that start inside this workgroup are also written out for the combine pass.
     __shared__ int32_t hc[kHeadsMax], hs[kHeadsMax];
-    const uint32_t d = plan.tab_dlog;
-    constexpr bool resid = (FMT == 2);
+    const uint32_t d = fmt_cell_log(plan.tab_dlog);
+    constexpr bool resid = (FMT == 2 || FMT == 3);
     const uint32_t cells_total = resid ? plan.entries >> d : 0u;
     uint32_t cell_lo = 0, n_cell = 0;
     if (resid) {
@@ -549,8 +574,13 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
             const int4 rec = record((g << 6) >> d);                                                     // wave-uniform
             const int2 p = tab_predict(rec, ((g << 6) & ((1u << d) - 1u)) + lane, d);
             const int32_t dc = c - p.x, ds = sn - p.y;
-            if (plan.check_flag && !(fits_bits(dc, 8) && fits_bits(ds, 8))) atomicOr(plan.check_flag, 1u);
-            reinterpret_cast<uint16_t *>(table)[idx] = (uint16_t)(((uint32_t)dc & 0xFFu) | (((uint32_t)ds & 0xFFu) << 8));
+            if constexpr (FMT == 3) {
+                if (plan.check_flag && !(fits_bits(dc, 4) && fits_bits(ds, 4))) atomicOr(plan.check_flag, 1u);
+                reinterpret_cast<uint8_t *>(table)[idx] = (uint8_t)(((uint32_t)dc & 0xFu) | (((uint32_t)ds & 0xFu) << 4));
+            } else {
+                if (plan.check_flag && !(fits_bits(dc, 8) && fits_bits(ds, 8))) atomicOr(plan.check_flag, 1u);
+                reinterpret_cast<uint16_t *>(table)[idx] = (uint16_t)(((uint32_t)dc & 0xFFu) | (((uint32_t)ds & 0xFFu) << 8));
+            }
         }
     }
 }
@@ -1097,7 +1127,7 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
     }
     const uint32_t part = __builtin_amdgcn_readfirstlane(threadIdx.x / kLanes);   // wave-uniform: kLanes is a multiple of 64
     const uint32_t lane_in_part = threadIdx.x % kLanes;
-    constexpr bool kLdsRec = BHW_TILE_LDSREC && FMT == 2 && NB >= 15 && kLanes == kTileLanes;
+    constexpr bool kLdsRec = BHW_TILE_LDSREC && (FMT == 2 || FMT == 3) && NB >= 15 && kLanes == kTileLanes;
     uint32_t rec_meta = 0;                                           // slot -> (K, g, j) of the record staging below, fetched first
     if constexpr (kLdsRec) rec_meta = kRecMeta.v[threadIdx.x & 63u];
     uint32_t rr[NR], starts[NR];
@@ -1115,7 +1145,7 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
     bool wraps = false;
     if constexpr (kLdsRec) {
         const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        const uint32_t d = cfg.tab_dlog;
+        const uint32_t d = fmt_cell_log(cfg.tab_dlog);
 #pragma unroll
         for (int b = 0; b < NR; ++b) {
             wraps |= starts[b] + (uint32_t)kLanes > H;
@@ -1152,7 +1182,7 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
 #ifndef BHW_TILE_VGPR_CONSTS
 #define BHW_TILE_VGPR_CONSTS 0      // measured: 1 is 1 % slower (profiles/r02_ab_tile_kernel_steps.txt) -- register pressure outweighs the cheaper operands
 #endif
-    ResidK rk{cfg.tab_dlog, (1u << cfg.tab_dlog) - 1u};
+    ResidK rk{fmt_cell_log(cfg.tab_dlog), (1u << fmt_cell_log(cfg.tab_dlog)) - 1u};
     uint32_t emask_v = emask, lq_v = lq;                            // per-gather shift / mask operands: VGPR copies (see ResidK)
 #if BHW_TILE_VGPR_CONSTS
     asm volatile("" : "+v"(rk.d), "+v"(rk.fmask), "+v"(emask_v), "+v"(lq_v));
@@ -2301,11 +2331,11 @@ int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table
         const dim3 grid((groups + plan.groups_per_wg - 1) / plan.groups_per_wg), block(kBuildThreads);
         // plain tables for every rotation count; the packed formats (whole-period tile calls at z_shr == 0, i.e. PW >= 22 and
         // therefore at least 21 rotations: the VHDL model at PW == W runs W - 1 of them) from 21 rotations on
-        const int fmt = c.tab_dlog == 0 ? 0 : c.tab_dlog == kPackLog ? 1 : 2;
+        const int fmt = fmt_of(c.tab_dlog);
         if (c.n_iter < 21 && fmt != 0) return (int)hipErrorInvalidValue;
 #define BHW_LAUNCH_BUILD(N, F) BHW_LAUNCH((k_table_build_shared<N, F>), grid, block, 0, st, plan, (void *)d_table)
 #define BHW_CASE(N) case N: BHW_LAUNCH_BUILD(N, 0); break;
-#define BHW_CASE_T(N) case N: if (fmt == 0) BHW_LAUNCH_BUILD(N, 0); else if (fmt == 1) BHW_LAUNCH_BUILD(N, 1); else BHW_LAUNCH_BUILD(N, 2); break;
+#define BHW_CASE_T(N) case N: if (fmt == 0) BHW_LAUNCH_BUILD(N, 0); else if (fmt == 1) BHW_LAUNCH_BUILD(N, 1); else if (fmt == 2) BHW_LAUNCH_BUILD(N, 2); else BHW_LAUNCH_BUILD(N, 3); break;
         switch (c.n_iter) {
             BHW_CASE(7) BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14)
             BHW_CASE(15) BHW_CASE(16) BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20)
@@ -2443,7 +2473,8 @@ int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c, con
     do {                                                                                                                 \
         if (c.tab_dlog == 0)             BHW_LAUNCH((k_table_combine_tile<NB, M, 0, F>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
         else if (c.tab_dlog == kPackLog) BHW_LAUNCH((k_table_combine_tile<NB, M, 1, F>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
-        else                             BHW_LAUNCH((k_table_combine_tile<NB, M, 2, F>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
+        else if (c.tab_dlog < kNibbleFlag) BHW_LAUNCH((k_table_combine_tile<NB, M, 2, F>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
+        else                             BHW_LAUNCH((k_table_combine_tile<NB, M, 3, F>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
     } while (0)
 #define BHW_LAUNCH_TILE_M(NB, M)                                                                                         \
     do {                                                                                                                 \
@@ -2476,7 +2507,7 @@ void bhwk_describe_table(const BhwCordicCfg &c, const BhwWinCfg &w, bool tiled, 
 {
     const uint32_t entries = 1u << (c.phi_width - 2 - c.z_shr);
     const bool fits = (c.dat_width + c.out_shr <= 34);
-    const int fmt = c.tab_dlog == 0 ? 0 : c.tab_dlog == kPackLog ? 1 : 2;
+    const int fmt = fmt_of(c.tab_dlog);
     if (fits && c.n_iter >= 7 && entries < (1u << 20) && c.tab_dlog == 0 && !c.tab_split) snprintf(build, len, "k_table_build_plain<%u>", c.n_iter);
     else if (entries >= 64 && fits && c.n_iter >= 2) snprintf(build, len, "k_table_build_shared<%u,%d>", c.n_iter, fmt);
     else snprintf(build, len, "k_table_build<%s>", c.wide ? "int64_t" : "int32_t");

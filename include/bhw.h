@@ -96,7 +96,8 @@ enum {
     BHW_TABLE_BEST     = 0, /* narrowest format that is exact for the configuration                 */
     BHW_TABLE_PLAIN    = 1, /* int2 (c, s) per entry, 8 bytes                                       */
     BHW_TABLE_DELTA16  = 2, /* at most: 4 bytes per entry (int16 differences to a 64-entry block head) */
-    BHW_TABLE_RESIDUAL = 3  /* at most: 2 bytes per entry against a linear predictor                 */
+    BHW_TABLE_RESIDUAL = 3, /* at most: 2 bytes per entry against a linear predictor (8-bit fields) */
+    BHW_TABLE_NIBBLE   = 4  /* at most: 1 byte per entry, the same predictor with 4-bit fields (what BEST tries first) */
 };
 
 /* Optional execution controls for the *_ex entry points. */

@@ -135,7 +135,9 @@ def test_packed_format_overflow_is_detected_on_the_device(torch):
     L = _dbg()
     flag = ctypes.c_uint32(7)
     for win, pw, w, model, dlog, expect in [(7, 26, 32, B.MODEL_HLS, 9, 0), (7, 26, 32, B.MODEL_CPP, 9, 0), (7, 24, 32, B.MODEL_HLS, 6, 0),
-                                            (7, 22, 32, B.MODEL_HLS, 6, 1), (7, 22, 32, B.MODEL_HLS, 9, 1), (4, 22, 24, B.MODEL_VHDL, 9, 0)]:
+                                            (7, 22, 32, B.MODEL_HLS, 6, 1), (7, 22, 32, B.MODEL_HLS, 9, 1), (4, 22, 24, B.MODEL_VHDL, 9, 0),
+                                            # 4-bit fields (16 + d): the HLS model's deviations stay within -5 .. 6, the cpp model's reach 10
+                                            (7, 26, 32, B.MODEL_HLS, 16 + 9, 0), (7, 26, 32, B.MODEL_CPP, 16 + 9, 1)]:
         p = B.make_params(win, pw, w, model=model)
         ws = torch.empty(B.lib().bhw_workspace_bytes(ctypes.byref(p), 0, 1 << pw, B.ALGO_TABLE), dtype=torch.uint8, device="cuda")
         assert L.bhw_dbg_check_table_format(ctypes.byref(p), 0, None, dlog, ctypes.c_void_p(ws.data_ptr()), ctypes.byref(flag)) == 0
@@ -150,9 +152,16 @@ def test_overflowing_format_falls_back_and_stays_exact(torch):
     d, ok16 = ctypes.c_uint32(), ctypes.c_uint32()
     assert L.bhw_dbg_table_format_info(ctypes.byref(p), ctypes.byref(d), ctypes.byref(ok16)) == 0
     assert d.value >= 7 and ok16.value == 1
-    assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), d.value, 0) == 0              # unknown so far
+    nib = 16 + d.value                                                                   # the 4-bit form is tried first
+    assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), nib, 0) == 0                  # unknown so far
+    assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), d.value, 0) == 0
     want = O.generate_mt(O.from_bhw(p), 0, 1 << 22)
     assert np.array_equal(bhw.generate(p, 0, 1 << 22, algo=B.ALGO_TABLE).cpu().numpy(), want)
+    v_nib = L.bhw_dbg_table_format_verdict(ctypes.byref(p), nib, 0)
+    assert v_nib in (1, 2)                                                               # decided on first use, either way
+    if v_nib == 1:
+        assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), nib, 2) == 2              # pretend it overflowed
+        assert np.array_equal(bhw.generate(p, 0, 1 << 22, algo=B.ALGO_TABLE).cpu().numpy(), want)   # 8-bit fields now
     assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), d.value, 0) == 1              # verified exact on first use
     assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), d.value, 2) == 2              # pretend it overflowed
     assert np.array_equal(bhw.generate(p, 0, 1 << 22, algo=B.ALGO_TABLE).cpu().numpy(), want)   # delta16 now
@@ -161,6 +170,17 @@ def test_overflowing_format_falls_back_and_stays_exact(torch):
     assert np.array_equal(bhw.generate(p, 0, 1 << 22, algo=B.ALGO_TABLE).cpu().numpy(), want)   # plain now
     assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), d.value, 1) == 1
     assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), 6, 1) == 1
+    assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), nib, v_nib) == v_nib
+
+
+def test_best_format_per_model(torch):
+    """BEST resolves to one byte per entry for the HLS model of the headline window and to two for the cpp model, whose
+    deviations do not fit four bits (decided by the device-side check of the first build, then cached)."""
+    import blackman_harris_win_amd as bhw
+    for model, want in ((B.MODEL_HLS, "table[nibble]"), (B.MODEL_CPP, "table[residual]")):
+        p = B.make_params(7, 26, 32, model=model)
+        bhw.generate(p, 0, 1 << 26, algo=B.ALGO_TABLE)
+        assert B.describe_plan(p, 0, 1 << 26, algo=B.ALGO_TABLE).startswith(want), B.describe_plan(p, 0, 1 << 26, algo=B.ALGO_TABLE)
 
 
 def test_out_tensors_are_validated(torch):

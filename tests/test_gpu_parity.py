@@ -540,14 +540,14 @@ def test_c3_full_64m(torch, golden):
 
 
 def test_packed_table_is_exact(torch, golden):
-    """The packed tables -- "residual" (2 bytes per entry against a linear predictor) and "delta16" (int16 differences to the first
-    entry of each 64-entry block) -- must give the same coefficients as the plain int2 table (bhw_exec.table_format)."""
+    """The packed tables -- "nibble" / "residual" (1 / 2 bytes per entry against a linear predictor) and "delta16" (int16 differences
+    to the first entry of each 64-entry block) -- must give the same coefficients as the plain int2 table (bhw_exec.table_format)."""
     import blackman_harris_win_amd as bhw
     for win, pw, w, model in ((7, 26, 32, 0), (7, 24, 32, 1), (4, 22, 24, 2), (5, 23, 29, 0), (7, 22, 28, 2), (3, 22, 30, 0),
                               (7, 22, 32, 0), (7, 25, 26, 1)):
         p = B.make_params(win, pw, w, model=model)
         outs = [bhw.generate(p, 12345, (1 << pw) + 99999, algo=B.ALGO_TABLE, table_format=f)
-                for f in (B.TABLE_PLAIN, B.TABLE_DELTA16, B.TABLE_RESIDUAL, B.TABLE_BEST)]
+                for f in (B.TABLE_PLAIN, B.TABLE_DELTA16, B.TABLE_RESIDUAL, B.TABLE_NIBBLE, B.TABLE_BEST)]
         for o in outs[1:]:
             assert bool((o == outs[0]).all()), (win, pw, w, model)
         del outs

@@ -11,7 +11,7 @@ for win, pw, w, model in ((7, 26, 32, 0), (7, 26, 32, 1), (7, 24, 30, 0)):
     p = bhw.make_params(win, pw, w, model=model)
     n = 1 << pw
     out = torch.empty(n, dtype=torch.int32, device="cuda")
-    fmts = [("residual", B.TABLE_RESIDUAL), ("delta16", B.TABLE_DELTA16), ("plain", B.TABLE_PLAIN)]
+    fmts = [("nibble", B.TABLE_NIBBLE), ("residual", B.TABLE_RESIDUAL), ("delta16", B.TABLE_DELTA16), ("plain", B.TABLE_PLAIN)]
     for _ in range(300):
         bhw.generate(p, 0, n, out=out)
     torch.cuda.synchronize()
