@@ -177,6 +177,15 @@ __device__ __forceinline__ int4 resid_record(const BhwCordicCfg &cfg, uint32_t u
 #endif
 }
 
+// residual / nibble format, the entry's residual word already loaded
+template <int FMT, bool LDS>
+__device__ __forceinline__ int2 tab_finish(const BhwCordicCfg &cfg, uint32_t u, const ResidK &rk, const char *lrec, uint32_t bias, uint32_t e)
+{
+    const int2 p = tab_predict(resid_record<LDS>(cfg, u, rk, lrec, bias), u & rk.fmask, rk.d);
+    if constexpr (FMT == 3) return make_int2(p.x + ((int32_t)(e << 28) >> 28), p.y + ((int32_t)(e << 24) >> 28));
+    else return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
+}
+
 template <int FMT, bool LDS = false>
 __device__ __forceinline__ int2 tab_fetch_k(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t idx, const ResidK &rk,
                                             const char *lrec = nullptr, uint32_t bias = 0u)
@@ -1094,6 +1103,28 @@ constexpr RecMeta make_rec_meta()
 }
 __device__ const RecMeta kRecMeta = make_rec_meta();
 
+// Two orders of the tile kernel's work, both measured (profiles/r02_ab_tile_memory_path.txt):
+//   harmonic-major (default for the HLS cosine-sum): every harmonic over the thread's three runs, 24 stores at the end;
+//   run-major (BHW_TILE_RUNMAJOR; default for the VHDL cosine-sum): one run at a time -- its six harmonics, then its eight
+//     stores -- with the nine residual words of the next run requested before the current one is worked on (BHW_TILE_PREFETCH,
+//     one register each).  8 sums live instead of 24: the VHDL-rule instance drops from 93 to 66 registers (5 -> 7 waves per
+//     SIMD) and runs 3.7 % faster; the HLS-rule instance (64 registers either way) ties with harmonic-major (0.1479 against
+//     0.1470 ms) and, without the prefetch, loses 10 % (fewer independent gathers in flight per harmonic).
+// Requesting all 27 residual words of a thread up front in harmonic-major order is slower (0.1562 ms: registers), as a
+// 320-thread / 64-lane tile shape with five waves per SIMD it ties (0.1467 ms): the kernel's remaining stall is not the latency
+// of its own loads.  (Two gathers per register through global_load_ubyte_d16 / _d16_hi is not available: with SRAM ECC a d16
+// load clears the other half.)
+#ifndef BHW_TILE_RUNMAJOR
+#define BHW_TILE_RUNMAJOR (NB >= 15 && (MODE == 2 || !FAST))      // also the 64-bit-product form (caller-scaled weights): no registers to spare otherwise
+#endif
+#ifndef BHW_TILE_PREFETCH
+#define BHW_TILE_PREFETCH (NB >= 15 && (MODE == 2 || !FAST))
+#endif
+__host__ __device__ constexpr int gather_order(int K, int b, int g)     // consumption order of the tile kernel's gathers, NR = 3
+{
+    return K == 1 ? b * 2 + g : K == 2 ? 6 + b : K == 3 ? 9 + b * 2 + g : K == 4 ? 15 + b : K == 5 ? 18 + b * 2 + g : 24 + b;
+}
+
 // Lane r in [0, E/2) owns the eight coefficients n = r + h*E/2 + j*E (h = 0,1; j = 0..3).  For even k the
 // two h-images share one gather (k*E/2 is a whole number of quadrants); for odd k the second image reads
 // entry t + E/2, another dense span of the same tile.
@@ -1143,6 +1174,29 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
     uint32_t rbias[kRecSets][NR];                                    // scalar: byte offset of "cell 0" of set si, run b in rec_s
     uint32_t qpack[NR];                                              // scalar: quadrant of set si, run b in bits 2 si, 2 si + 1
     bool wraps = false;
+    uint32_t cls[NR];                                                // residue class of r in the split layout (odd harmonics)
+#pragma unroll
+    for (int b = 0; b < NR; ++b) cls[b] = split_class<FMT>(rr[b], lq);
+    constexpr bool kPrefetch = BHW_TILE_PREFETCH && kLdsRec && NR == 3;
+    uint32_t land[kPrefetch ? 27 : 1];                               // residual words, one per gather (gather_order)
+    auto issue_runs = [&](auto run_tag) {
+        constexpr int B0 = decltype(run_tag)::value < 0 ? 0 : decltype(run_tag)::value, B1 = decltype(run_tag)::value < 0 ? NR : B0 + 1;
+#define BHW_TILE_ISSUE(K)                                                                                \
+        if (win.n_terms > K) {                                                                           \
+            constexpr int NG = (K & 1) ? 2 : 1;                                                          \
+            constexpr int KC = (K % 4 == 0) ? 4 : (K % 2 == 0) ? 2 : 0;                                  \
+            _Pragma("unroll") for (int b = B0; b < B1; ++b) {                                            \
+                _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                         \
+                    const uint32_t u = ((uint32_t)K * (rr[b] + (uint32_t)g * H)) & emask;                \
+                    const uint32_t idx2 = (K & 1) ? ((u >> (cls[b] & 31u)) | cls[b]) & ~1u : tab_index<KC, 1>(u, lq, 1u) << 1; \
+                    land[gather_order(K, b, g)] = FMT == 3 ? (uint32_t)ld_off<uint8_t>(table, idx2 >> 1) : (uint32_t)ld_off<uint16_t>(table, idx2); \
+                }                                                                                        \
+            }                                                                                            \
+        }
+        BHW_TILE_ISSUE(1) BHW_TILE_ISSUE(2) BHW_TILE_ISSUE(3) BHW_TILE_ISSUE(4) BHW_TILE_ISSUE(5) BHW_TILE_ISSUE(6)
+#undef BHW_TILE_ISSUE
+        __builtin_amdgcn_sched_barrier(0);                           // the loads stay here (left alone the scheduler sinks them to their uses)
+    };
     if constexpr (kLdsRec) {
         const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const uint32_t d = fmt_cell_log(cfg.tab_dlog);
@@ -1158,6 +1212,12 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
                 qpack[b] |= ((th0 >> lq) & 3u) << (2 * si);
                 wraps |= u0 + K * (uint32_t)(kLanes - 1) > emask;
                 rbias[si][b] = (((wave * NR + b) * kRecPerRun + (uint32_t)rec_set_base(si)) << 4) - ((u0 >> d) << 4);
+            }
+        }
+        if constexpr (kPrefetch) {
+            if (!wraps) {
+                if constexpr (BHW_TILE_RUNMAJOR) issue_runs(std::integral_constant<int, 0>{});   // run 0 now, run b + 1 while run b is worked on
+                else issue_runs(std::integral_constant<int, -1>{});
             }
         }
         if (!wraps) {
@@ -1187,40 +1247,46 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
 #if BHW_TILE_VGPR_CONSTS
     asm volatile("" : "+v"(rk.d), "+v"(rk.fmask), "+v"(emask_v), "+v"(lq_v));
 #endif
-    uint32_t cls[NR];                                                // residue class of r in the split layout (odd harmonics)
-#pragma unroll
-    for (int b = 0; b < NR; ++b) cls[b] = split_class<FMT>(rr[b], lq);
+    // Run-major order (BHW_TILE_RUNMAJOR): one run at a time -- its six harmonics, then its eight stores -- instead of every
+    // harmonic over the three runs and 24 stores at the end: 8 sums live instead of 24, and the stores of a wave are spread
+    // over its life.  `run_tag` selects the runs a pass covers: -1 all (harmonic-major), else that one.
     acc_t acc[NR][2][4];
+    auto init_acc = [&](auto run_tag) {
+        constexpr int B0 = decltype(run_tag)::value < 0 ? 0 : decltype(run_tag)::value, B1 = decltype(run_tag)::value < 0 ? NR : B0 + 1;
 #pragma unroll
-    for (int b = 0; b < NR; ++b)
+        for (int b = B0; b < B1; ++b)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (MODE == 2) acc[b][h][j] = Sum32{win.aa[0] >> 2, win.aa[0] & 3};
-                else acc[b][h][j] = win.aa[0];
-            }
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (MODE == 2) acc[b][h][j] = Sum32{win.aa[0] >> 2, win.aa[0] & 3};
+                    else acc[b][h][j] = win.aa[0];
+                }
+    };
 
-    auto harmonics = [&](auto lds_tag) {
+    auto harmonics = [&](auto lds_tag, auto run_tag) {
     constexpr bool LDS = decltype(lds_tag)::value;
+    constexpr int B0 = decltype(run_tag)::value < 0 ? 0 : decltype(run_tag)::value, B1 = decltype(run_tag)::value < 0 ? NR : B0 + 1;
     const char *lrec = reinterpret_cast<const char *>(rec_s);
 #define BHW_TILE_HARMONIC(K)                                                                             \
     if (win.n_terms > K) {                                                                               \
         constexpr int NG = (K & 1) ? 2 : 1;                                                              \
         constexpr int KC = (K % 4 == 0) ? 4 : (K % 2 == 0) ? 2 : 0;   /* split layout only exists at z_shr == 0 */ \
         int2 cs[NR][NG];                                                                                 \
-        _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
+        _Pragma("unroll") for (int b = B0; b < B1; ++b) {                                                 \
             _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                             \
                 const uint32_t theta = (uint32_t)K * (rr[b] + (uint32_t)g * H);                          \
                 const uint32_t bias = rbias[rec_set_index(K, g)][b];                                     \
-                if constexpr (NB > 1 && (K & 1)) cs[b][g] = tab_load_class<FMT, LDS>(cfg, table, theta & emask_v, cls[b], rk, lrec, bias); \
+                if constexpr (kPrefetch && LDS) {                                                        \
+                    cs[b][g] = tab_finish<FMT, true>(cfg, theta & emask_v, rk, lrec, bias, land[gather_order(K, b, g)]); \
+                } else if constexpr (NB > 1 && (K & 1)) cs[b][g] = tab_load_class<FMT, LDS>(cfg, table, theta & emask_v, cls[b], rk, lrec, bias); \
                 else if constexpr (NB > 1) {                                                             \
                     const uint32_t u = theta & emask_v;                                                  \
                     cs[b][g] = tab_fetch_k<FMT, LDS>(cfg, table, u, tab_index<KC, 1>(u, lq, 1u), rk, lrec, bias); \
                 } else cs[b][g] = tab_load<KC, FMT, -1>(cfg, table, (theta & emask) >> cfg.z_shr, lq - cfg.z_shr); \
             }                                                                                            \
         }                                                                                                \
-        _Pragma("unroll") for (int b = 0; b < NR; ++b) {                                                 \
+        _Pragma("unroll") for (int b = B0; b < B1; ++b) {                                                 \
             int32_t sv[4];                                                                               \
             /* only quadrant bits 0,1 of theta >> lq are used */                                         \
             const int32_t aK = FAST ? (int32_t)((uint32_t)win.aa[K] << (34u - W)) : win.aa[K];          \
@@ -1258,15 +1324,19 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
     BHW_TILE_HARMONIC(6)
 #undef BHW_TILE_HARMONIC
     };
-    if constexpr (kLdsRec) {
-        if (wraps) harmonics(std::false_type{});                     // block-uniform
-        else harmonics(std::true_type{});
-    } else harmonics(std::false_type{});
+    auto run_harmonics = [&](auto run_tag) {
+        if constexpr (kLdsRec) {
+            if (wraps) harmonics(std::false_type{}, run_tag);        // block-uniform
+            else harmonics(std::true_type{}, run_tag);
+        } else harmonics(std::false_type{}, run_tag);
+    };
 
     auto final_value = [&](int b, int h, int j) -> int32_t {
         if constexpr (MODE == 2) return w32_final<BHW_COMBINE_VHDL>(acc[b][h][j], W, win.n_terms);
         else return (int32_t)((uint32_t)acc[b][h][j] << (32u - W)) >> (32u - W);   // (win_t)(...) wrap to W bits
     };
+    auto store_runs = [&](auto run_tag) {
+    constexpr int B0 = decltype(run_tag)::value < 0 ? 0 : decltype(run_tag)::value, B1 = decltype(run_tag)::value < 0 ? NR : B0 + 1;
     if (win.apply_x == nullptr) {                                    // wave-uniform
         // image (h, j) starts at out + h*H + j*E, a scalar address the lane adds its 32-bit byte offset r * 4 to (saddr stores;
         // the empty asm keeps the compiler from folding the image offset back into a 64-bit vector add per store)
@@ -1279,7 +1349,7 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
                     asm volatile("" : "+s"(img_off));
                     int32_t *img = out + img_off;
 #pragma unroll
-                    for (int b = 0; b < NR; ++b) {
+                    for (int b = B0; b < B1; ++b) {
                         int32_t v;
                         if constexpr (MODE != 2 && decltype(full_width)::value) v = acc_value(acc[b][h][j]);   // W == 32: nothing to wrap
                         else v = final_value(b, h, j);
@@ -1299,7 +1369,7 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
     } else {
         // Fused apply (emit()): one run at a time, its eight x samples fetched together before they are used
 #pragma unroll
-        for (int b = 0; b < NR; ++b) {
+        for (int b = B0; b < B1; ++b) {
             int32_t xv[2][4];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -1315,6 +1385,16 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
                     out[(uint64_t)(rr[b] + (uint32_t)h * H + (uint32_t)j * E)] =
                         (int32_t)(((int64_t)xv[h][j] * (int64_t)final_value(b, h, j)) >> win.apply_shift);
         }
+    }
+    };
+    if constexpr (BHW_TILE_RUNMAJOR && NR == 3) {
+        if constexpr (kPrefetch) { if (!wraps) issue_runs(std::integral_constant<int, 1>{}); }
+        init_acc(std::integral_constant<int, 0>{}); run_harmonics(std::integral_constant<int, 0>{}); store_runs(std::integral_constant<int, 0>{});
+        if constexpr (kPrefetch) { if (!wraps) issue_runs(std::integral_constant<int, 2>{}); }
+        init_acc(std::integral_constant<int, 1>{}); run_harmonics(std::integral_constant<int, 1>{}); store_runs(std::integral_constant<int, 1>{});
+        init_acc(std::integral_constant<int, 2>{}); run_harmonics(std::integral_constant<int, 2>{}); store_runs(std::integral_constant<int, 2>{});
+    } else {
+        init_acc(std::integral_constant<int, -1>{}); run_harmonics(std::integral_constant<int, -1>{}); store_runs(std::integral_constant<int, -1>{});
     }
 }
 
