@@ -790,7 +790,19 @@ int bhw_sincos_to_host(const bhw_params *p, int device, uint64_t theta0, uint64_
 }
 
 // Development hooks (not part of the ABI in include/bhw.h): the two passes of the table strategy on their own,
-// for overlap experiments (tools/overlap_probe.py).
+// for overlap experiments (tools/overlap_probe.py).  They use the narrowest table format already verified for the
+// configuration (a bhw_generate_device call of the same parameters settles it), plain otherwise.
+static void dbg_verified_format(const bhw_params *p, BhwCordicCfg &c, bool tiled, const void *ws)
+{
+    uint32_t cand[kMaxFormats];
+    const int n = table_format_candidates(c, tiled, BHW_TABLE_BEST, cand);
+    c.tab_dlog = 0;
+    for (int i = 0; i < n; ++i)
+        if (cand[i] && fmt_verdict(p, cand[i]) == kFmtOk) { c.tab_dlog = cand[i]; break; }
+    c.tab_coarse = c.tab_dlog ? (const void *)((const char *)ws + table_entries(c) * 4ull) : nullptr;
+    c.tab_check = nullptr;
+}
+
 int bhw_dbg_table_build(const bhw_params *p, int device, void *stream, void *ws)
 {
     if (validate(p)) return BHW_ERR_BADARG;
@@ -799,6 +811,7 @@ int bhw_dbg_table_build(const bhw_params *p, int device, void *stream, void *ws)
     BhwWinCfg w;
     resolve_window(p, w);
     c.tab_split = (bhwk_tile_applicable(c, w) && c.z_shr == 0) ? 1u : 0u;
+    dbg_verified_format(p, c, bhwk_tile_applicable(c, w), ws);
     DeviceGuard guard(device);
     BhwLaunch l{device, stream};
     return bhwk_table_build(l, c, (int32_t *)ws);
@@ -815,6 +828,7 @@ int bhw_dbg_table_combine(const bhw_params *p, int device, void *stream, const v
     BhwLaunch l{device, stream};
     if (bhwk_tile_applicable(c, w)) {
         c.tab_split = c.z_shr == 0 ? 1u : 0u;
+        dbg_verified_format(p, c, true, ws);
         return bhwk_table_combine_tile(l, c, w, (const int32_t *)ws, d_out);
     }
     return bhwk_table_combine_fold(l, c, w, (const int32_t *)ws, d_out);
