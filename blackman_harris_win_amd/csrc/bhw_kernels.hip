@@ -583,6 +583,8 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
             const int4 rec = record((g << 6) >> d);                                                     // wave-uniform
             const int2 p = tab_predict(rec, ((g << 6) & ((1u << d) - 1u)) + lane, d);
             const int32_t dc = c - p.x, ds = sn - p.y;
+            // (byte-wide stores make this variant 2 % slower than the two-byte one at equal instruction counts, 72.3 against 70.7 us;
+            // staging a workgroup's entries in shared memory and writing them as 16-byte packets costs more than it saves, +1.5 us)
             if constexpr (FMT == 3) {
                 if (plan.check_flag && !(fits_bits(dc, 4) && fits_bits(ds, 4))) atomicOr(plan.check_flag, 1u);
                 reinterpret_cast<uint8_t *>(table)[idx] = (uint8_t)(((uint32_t)dc & 0xFu) | (((uint32_t)ds & 0xFu) << 4));
@@ -818,11 +820,11 @@ __device__ __forceinline__ int32_t w32_final(const Sum32 &acc, uint32_t W, uint3
 // 32 x 32 product of that pre-shifted weight -- one v_mul_hi_i32 instead of v_mad_i64_i32 + v_ashrrev_i64, the low half telling
 // whether the shifted-out bits were zero.  The caller passes the pre-shifted weight as `a`.
 #ifndef BHW_TILE_ROT
-#define BHW_TILE_ROT 1      // how the quadrant rotation is written: 0 as the compiler likes it, 1 opaque bits (-1.7 %), 2/3 selects in VOP3 form via inline assembly (-1 %), 4 timing only
+#define BHW_TILE_ROT 1      // how the quadrant rotation is written: 0 plain selects (the compiler turns them into three compare + select pairs per slot), 1 quadrant bits opaque to it (-1.7 %)
 #endif
 template <int K, int MODE, int QBASE = 0, int QBITS = 2, bool FAST = false>
 __device__ __forceinline__ void tile_harmonic(const BhwCordicCfg &cfg, const int32_t a, const uint32_t W, const int2 cs, const uint32_t q,
-                                              int32_t (&sv)[4], const uint32_t qshift = 0u)
+                                              int32_t (&sv)[4])
 {
     int32_t p0, p1, p2, p3;                                // cosine term in quadrant 0..3: c, -s, -c, s
     if constexpr (FAST && MODE != 2) {
@@ -868,39 +870,7 @@ __device__ __forceinline__ void tile_harmonic(const BhwCordicCfg &cfg, const int
         }
     }
     // rotate the four candidates by q so that image j (quadrant q + j*K) reads a fixed slot
-#if BHW_TILE_ROT == 4
-    sv[0] = p0; sv[1] = p1; sv[2] = p2; sv[3] = p3;                  // timing experiment only: no rotation at all (wrong results)
-#elif BHW_TILE_ROT >= 2
-    // one lane mask per quadrant bit in a scalar register pair, selects in the VOP3 form that reads it (the s_nop covers the two
-    // wait states between a vector compare and a select that reads its result as a mask)
-    auto rot1 = [](uint32_t bit, int32_t a0, int32_t a1, int32_t a2, int32_t a3, int32_t &o0, int32_t &o1, int32_t &o2, int32_t &o3) {
-        uint64_t m;
-        asm("v_cmp_ne_u32_e64 %4, 0, %5\n\ts_nop 1\n\t"
-            "v_cndmask_b32_e64 %0, %6, %7, %4\n\tv_cndmask_b32_e64 %1, %7, %8, %4\n\t"
-            "v_cndmask_b32_e64 %2, %8, %9, %4\n\tv_cndmask_b32_e64 %3, %9, %6, %4"
-            : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&s"(m) : "v"(bit), "v"(a0), "v"(a1), "v"(a2), "v"(a3));
-    };
-    auto rot2 = [](uint32_t bit, int32_t a0, int32_t a1, int32_t a2, int32_t a3, int32_t &o0, int32_t &o1, int32_t &o2, int32_t &o3) {
-        uint64_t m;
-        asm("v_cmp_ne_u32_e64 %4, 0, %5\n\ts_nop 1\n\t"
-            "v_cndmask_b32_e64 %0, %6, %8, %4\n\tv_cndmask_b32_e64 %1, %7, %9, %4\n\t"
-            "v_cndmask_b32_e64 %2, %8, %6, %4\n\tv_cndmask_b32_e64 %3, %9, %7, %4"
-            : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&s"(m) : "v"(bit), "v"(a0), "v"(a1), "v"(a2), "v"(a3));
-    };
-    if constexpr (QBITS == 2) {
-        static_assert(QBASE == 0, "two-bit rotation takes q as it is");
-        int32_t r0, r1, r2, r3;
-        rot1(q & (1u << qshift), p0, p1, p2, p3, r0, r1, r2, r3);
-        rot2(q & (2u << qshift), r0, r1, r2, r3, sv[0], sv[1], sv[2], sv[3]);
-    } else if constexpr (QBITS == 0) {
-        const int32_t p[4] = {p0, p1, p2, p3};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sv[i] = p[(i + QBASE) & 3];
-    } else {
-        const int32_t p[4] = {p0, p1, p2, p3};
-        rot1(((QBASE & 1) ? ~q : q) & (1u << qshift), p[QBASE & 3], p[(QBASE + 1) & 3], p[(QBASE + 2) & 3], p[(QBASE + 3) & 3], sv[0], sv[1], sv[2], sv[3]);
-    }
-#elif BHW_TILE_ROT == 1
+#if BHW_TILE_ROT == 1
     // quadrant bits as opaque 0 / 1 values: one compare per bit, plain selects (left to itself the compiler turns the selects into
     // an indexed read of the four candidates and that into a chain of three compare + select pairs per slot)
     if constexpr (QBITS == 2) {
@@ -1303,12 +1273,10 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
                 }                                                                                        \
                 continue;                                                                                \
             }                                                                                            \
-            if constexpr (BHW_TILE_ROT == 3) tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0), FAST>(cfg, aK, W, cs[b][0], (uint32_t)K * rr[b], sv, lq); \
-            else tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0), FAST>(cfg, aK, W, cs[b][0], ((uint32_t)K * rr[b]) >> lq_v, sv); \
+            tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0), FAST>(cfg, aK, W, cs[b][0], ((uint32_t)K * rr[b]) >> lq_v, sv); \
             tile_accumulate<K, 0, FAST>(sv, acc[b][0]);                                                        \
             if constexpr (NG == 2) {                                                                     \
-                if constexpr (BHW_TILE_ROT == 3) tile_harmonic<K, MODE, ring_qbase(K, 1), ring_qbits(K, 1), FAST>(cfg, aK, W, cs[b][NG - 1], (uint32_t)K * (rr[b] + H), sv, lq); \
-                else tile_harmonic<K, MODE, ring_qbase(K, 1), ring_qbits(K, 1), FAST>(cfg, aK, W, cs[b][NG - 1], ((uint32_t)K * (rr[b] + H)) >> lq_v, sv); \
+                tile_harmonic<K, MODE, ring_qbase(K, 1), ring_qbits(K, 1), FAST>(cfg, aK, W, cs[b][NG - 1], ((uint32_t)K * (rr[b] + H)) >> lq_v, sv); \
                 tile_accumulate<K, 0, FAST>(sv, acc[b][1]);                                                    \
             } else {                                                                                     \
                 /* even K: the second half-period image reads the same entry K/2 quadrants further on */ \
