@@ -480,7 +480,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
     // the first wave runs the group prefixes; cells that start inside this workgroup are also written out for the combine pass.
     __shared__ int32_t hc[kHeadsMax], hs[kHeadsMax];
     const uint32_t d = fmt_cell_log(plan.tab_dlog);
-    constexpr bool resid = (FMT == 2 || FMT == 3);
+    constexpr bool resid = (FMT == 2 || FMT == 3);            // (FMT 4: no table, see the store below)
     const uint32_t cells_total = resid ? plan.entries >> d : 0u;
     uint32_t cell_lo = 0, n_cell = 0;
     if (resid) {
@@ -572,7 +572,21 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
         const int32_t c = (int32_t)(x >> plan.out_shr), sn = (int32_t)(y >> plan.out_shr);
         const int2 head = make_int2(__builtin_amdgcn_readfirstlane(c), __builtin_amdgcn_readfirstlane(sn));   // leaf 0 of the group
         const uint32_t idx = idx_a + g * idx_m;
-        if constexpr (FMT == 0) {
+        if constexpr (FMT == 4) {
+            // sin / cos sweep over one whole period (bhwk_sincos): no table -- the leaf's first-quadrant pair goes out as its four
+            // quadrant images, phase q*E + u at stream position (phase - theta0) mod N.  table = d_sin, tab_coarse = d_cos (either
+            // may be NULL), pad0 = the model's negation rule, pad = theta0 mod N.
+            const uint32_t u = (g << 6) + lane, nmask = 4u * plan.entries - 1u;
+            int32_t *d_sin = reinterpret_cast<int32_t *>(table), *d_cos = reinterpret_cast<int32_t *>(const_cast<void *>(plan.tab_coarse));
+#pragma unroll
+            for (uint32_t q = 0; q < 4u; ++q) {
+                int32_t oc, os;
+                quadrant_map(q, c, sn, plan.pad0, oc, os);
+                const uint32_t i = (q * plan.entries + u - plan.pad) & nmask;
+                if (d_sin) d_sin[i] = os;
+                if (d_cos) d_cos[i] = oc;
+            }
+        } else if constexpr (FMT == 0) {
             reinterpret_cast<int2 *>(table)[idx] = make_int2(c, sn);
         } else if constexpr (FMT == 1) {
             const int32_t dc = c - head.x, ds = sn - head.y;
@@ -2277,6 +2291,42 @@ int bhwk_sincos(const BhwLaunch &l, const BhwCordicCfg &c, uint64_t theta0, uint
     if (!count) return 0;
     BHW_SET_DEVICE(l);
     hipStream_t st = (hipStream_t)l.stream;
+    // One whole period from 2^16 phases on: the shared-prefix chains of the table build (one chain per first-quadrant angle, a
+    // 64-leaf group's common rotations run once) with the four quadrant images written straight out -- a quarter of the chains of
+    // the per-phase kernel and about half of their rotations.
+#ifndef BHW_SINCOS_FOLD_MIN_PW
+#define BHW_SINCOS_FOLD_MIN_PW 16
+#endif
+    if (c.dat_width + c.out_shr <= 34 && c.n_iter >= 7 && c.z_shr == 0 && c.phi_width >= BHW_SINCOS_FOLD_MIN_PW &&
+        count == (1ull << c.phi_width)) {
+        BhwBuildPlan plan;
+        for (uint32_t k = 0; k < 32; ++k) plan.lut[k] = (uint32_t)c.lut[k];
+        plan.entries = 1u << (c.phi_width - 2);
+        plan.n_iter = c.n_iter;
+        plan.z_shl = c.z_shl;
+        plan.out_shr = c.out_shr;
+        plan.log2_entries = c.phi_width - 2;
+        plan.tab_split = 0;
+        plan.tab_dlog = 0;
+        plan.pad0 = c.ones_neg;
+        plan.tab_coarse = d_cos;
+        plan.x0 = c.x0;
+        plan.check_flag = nullptr;
+        const unsigned groups = plan.entries >> 6;
+        plan.groups_per_wg = groups >= 64u * 1024u ? 64u : groups >= 16u * 1024u ? 16u : 4u;
+        plan.pad = (uint32_t)(theta0 & ((1ull << c.phi_width) - 1ull));
+        const dim3 grid((groups + plan.groups_per_wg - 1) / plan.groups_per_wg), block(kBuildThreads);
+        switch (c.n_iter) {
+#define BHW_CASE(N) case N: BHW_LAUNCH((k_table_build_shared<N, 4>), grid, block, 0, st, plan, (void *)d_sin); break;
+            BHW_CASE(7) BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14)
+            BHW_CASE(15) BHW_CASE(16) BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20) BHW_CASE(21) BHW_CASE(22)
+            BHW_CASE(23) BHW_CASE(24) BHW_CASE(25) BHW_CASE(26) BHW_CASE(27) BHW_CASE(28) BHW_CASE(29) BHW_CASE(30)
+            BHW_CASE(31) BHW_CASE(32)
+#undef BHW_CASE
+        default: return (int)hipErrorInvalidValue;
+        }
+        return finish(hipSuccess);
+    }
     if (c.dat_width + c.out_shr <= 34 && c.n_iter >= 7) {
         const dim3 grid(grid_for(count)), block(kBlock);
         switch (c.n_iter) {

@@ -580,3 +580,21 @@ def test_c3_model_cpp_full_sincos_quadrant_property(torch):
     ws, wc = O.sincos(O.from_bhw(p), q - 500, 1000)
     s, c = bhw.cordic(p, q - 500, 1000)
     assert np.array_equal(s.cpu().numpy(), ws) and np.array_equal(c.cpu().numpy(), wc)
+
+
+@pytest.mark.parametrize("model", [B.MODEL_HLS, B.MODEL_CPP, B.MODEL_VHDL])
+def test_whole_period_sincos_sweep_through_shared_prefixes(torch, model):
+    """cordic() over exactly one period from 2^16 phases on runs the shared-prefix chains of the table build with the four
+    quadrant images written straight out (bhwk_sincos): every phase against the oracle, any start phase, either output alone;
+    the per-phase kernel (count != N) gives the same values."""
+    import blackman_harris_win_amd as bhw
+    for pw, w, theta0 in ((16, 16, 0), (18, 24, 12345), (22, 32, (1 << 22) - 7), (20, 18, 3 << 20)):
+        if model == B.MODEL_HLS and pw > w + 2:
+            continue
+        p = B.make_params(1, pw, w, model=model, precision=2 if model == B.MODEL_VHDL else 1)
+        n = 1 << pw
+        ws, wc = O.sincos_mt(O.from_bhw(p), theta0, n)
+        gs, gc = bhw.cordic(p, theta0, n)
+        assert np.array_equal(gs.cpu().numpy(), ws) and np.array_equal(gc.cpu().numpy(), wc), (model, pw, w, theta0)
+        hs, hc = bhw.cordic(p, theta0, n + 1)                       # one more phase: the per-phase kernel
+        assert bool((hs[:n] == gs).all()) and bool((hc[:n] == gc).all())
