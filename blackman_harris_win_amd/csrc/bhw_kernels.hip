@@ -2904,32 +2904,36 @@ __global__ __launch_bounds__(kBlock) void k_sincos_prerot(BhwPrerotCfg c, uint64
 }
 
 // cordic_atan2 (src/cordic_atan2.vhd:126-213).  The B = ANGLE_WIDTH + PRECISION bit registers do wrap (PRECISION 1 with
-// full-scale inputs), so the state is kept shifted left by 64 - B: 64-bit overflow then *is* the B-bit wrap, and the only
-// extra work is clearing the 64 - B low bits that an arithmetic right shift drags in.
+// full-scale inputs), so the state is kept shifted left by (word size - B): overflow of the word then *is* the B-bit wrap, and
+// the only extra work is clearing the low bits that an arithmetic right shift drags in.  U = uint32_t when B <= 32 (half the
+// instructions of the 64-bit form: every shift, add and select is one 32-bit operation), uint64_t otherwise.
+template <typename U>
 __global__ __launch_bounds__(kBlock) void k_atan2(BhwAtan2Cfg c, uint64_t count, const int32_t *__restrict__ d_x,
                                                    const int32_t *__restrict__ d_y, int32_t *__restrict__ d_phi)
 {
+    using S = typename std::make_signed<U>::type;
+    constexpr uint32_t WB = 8u * sizeof(U);
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= count) return;
-    const uint32_t IW = c.input_width, AW = c.angle_width, B = AW + c.precision, sh = 64u - B;
+    const uint32_t IW = c.input_width, AW = c.angle_width, B = AW + c.precision, sh = WB - B;
     const uint64_t im = (1ull << IW) - 1ull;                             // IW <= 32
     const uint64_t ux = (uint64_t)(int64_t)d_x[i] & im, uy = (uint64_t)(int64_t)d_y[i] & im;
     const uint32_t sx = (uint32_t)(ux >> (IW - 1)) & 1u, sy = (uint32_t)(uy >> (IW - 1)) & 1u;
     const uint64_t lowm = (1ull << (AW - 1)) - 1ull;
-    const uint64_t keep = ~((1ull << sh) - 1ull);
-    uint64_t X = ((sx ? ~ux : ux) & lowm) << sh;                         // :142-147
-    uint64_t Y = ((sy ? ~uy : uy) & lowm) << sh;
-    uint64_t Z = 0;                                                     // :152
+    const U keep = (U)~(((U)1 << sh) - (U)1);
+    U X = (U)((sx ? ~ux : ux) & lowm) << sh;                             // :142-147
+    U Y = (U)((sy ? ~uy : uy) & lowm) << sh;
+    U Z = 0;                                                            // :152
     for (uint32_t ii = 0; ii + 1 < AW; ++ii) {                          // :172-190
-        const uint64_t xs = (uint64_t)((int64_t)X >> ii) & keep, ys = (uint64_t)((int64_t)Y >> ii) & keep;
-        const uint64_t rom = (uint64_t)c.lut[ii] << sh;
-        const bool pos = (int64_t)Y >= 0;
+        const U xs = (U)((S)X >> ii) & keep, ys = (U)((S)Y >> ii) & keep;
+        const U rom = (U)c.lut[ii] << sh;
+        const bool pos = (S)Y >= 0;
         X = pos ? X + ys : X - ys;
         Y = pos ? Y - xs : Y + xs;
         Z = pos ? Z - rom : Z + rom;
     }
     // :194  sigZ(ANGLE_WIDTH-1)(B-1 downto PRECISION): the top ANGLE_WIDTH bits of the B-bit word
-    const int64_t phi = (int64_t)Z >> (64u - AW);
+    const int64_t phi = (int64_t)((S)Z >> (WB - AW));
     const int64_t pi_word = (int64_t)1 << (AW - 2);                     // PHI_PI :112
     const uint32_t quad = (sx << 1) | sy;                               // :126-128
     const int64_t out = quad == 0u ? phi : quad == 1u ? phi + pi_word : quad == 2u ? -phi : phi - pi_word;   // :207-213
@@ -2957,7 +2961,8 @@ int bhwk_atan2(const BhwLaunch &l, const BhwAtan2Cfg &c, uint64_t count, const i
 {
     if (!count) return 0;
     BHW_SET_DEVICE(l);
-    BHW_LAUNCH(k_atan2, dim3(grid_for(count)), dim3(kBlock), 0, (hipStream_t)l.stream, c, count, d_x, d_y, d_phi);
+    if (c.angle_width + c.precision <= 32u) BHW_LAUNCH(k_atan2<uint32_t>, dim3(grid_for(count)), dim3(kBlock), 0, (hipStream_t)l.stream, c, count, d_x, d_y, d_phi);
+    else                                    BHW_LAUNCH(k_atan2<uint64_t>, dim3(grid_for(count)), dim3(kBlock), 0, (hipStream_t)l.stream, c, count, d_x, d_y, d_phi);
     return finish(hipSuccess);
 }
 
