@@ -2903,6 +2903,65 @@ __global__ __launch_bounds__(kBlock) void k_sincos_prerot(BhwPrerotCfg c, uint64
     if (d_cos) d_cos[i] = (int32_t)(x >> (c.size - NITER));
 }
 
+// The same generators over one whole period (count == 2^PHASE_WIDTH, any start phase): inside a quadrant consecutive phases are
+// consecutive angles on one start vector, so a group of 64 phases shares its rotations until the first one whose threshold
+// falls inside the group -- exactly the structure of k_table_build_shared, with the quadrant's start vector per group.  Phase 1:
+// one lane per group runs the shared prefix (these are the expensive rotations: 64-bit select-and-add below stage 16) and parks
+// it in LDS; phase 2: one wave per group, one lane per phase, only the remaining stages.
+template <int NITER>
+__global__ __launch_bounds__(kBuildThreads) void k_prerot_sweep(BhwPrerotCfg c, uint32_t theta0, int32_t *__restrict__ d_sin, int32_t *__restrict__ d_cos)
+{
+    __shared__ int64_t gx[kGroupsPerWg], gy[kGroupsPerWg], gz[kGroupsPerWg];
+    __shared__ int32_t gk[kGroupsPerWg];
+    const uint32_t PW = c.phi_width, zs = c.dwph - PW;
+    const uint32_t group0 = blockIdx.x * kGroupsPerWg, n_groups = 1u << (PW - 6);
+    constexpr int kmax = NITER < kPrefixMax ? NITER : kPrefixMax;
+    if (threadIdx.x < (uint32_t)kGroupsPerWg && group0 + threadIdx.x < n_groups) {
+        const uint64_t theta = (uint64_t)(group0 + threadIdx.x) << 6;       // first phase of the group
+        const uint32_t q = (uint32_t)(theta >> (PW - 2)) & 3u;              // dds48 :167
+        const uint64_t low = theta & ((1ull << (PW - 2)) - 1ull);
+        uint64_t t = theta;                                                 // init_t :169-186
+        int64_t x = c.gain, y = 0;                                          // init_x / init_y :191-216
+        if (q == 1u)      { t = low;                      x = 0; y = -c.gain; }
+        else if (q == 2u) { t = (3ull << (PW - 2)) | low; x = 0; y = c.gain; }
+        int64_t zf = wrap_bits((int64_t)(t << zs), c.dwph);                 // init_z: sign-extended phase
+        const int64_t span = (int64_t)63 << zs;
+        int k = 0;
+        bool live = true;
+#define BHW_PRE(II)                                                                        \
+        if constexpr (kmax > II) {                                                          \
+            if (live) {                                                                     \
+                if ((zf < 0) != (zf + span < 0)) live = false;                              \
+                else { prerot_step<II>(x, y, zf, c.lut[II], II + 1 == NITER); k = II + 1; } \
+            }                                                                               \
+        }
+        BHW_PRE(0) BHW_PRE(1) BHW_PRE(2) BHW_PRE(3) BHW_PRE(4) BHW_PRE(5) BHW_PRE(6) BHW_PRE(7) BHW_PRE(8) BHW_PRE(9)
+        BHW_PRE(10) BHW_PRE(11) BHW_PRE(12) BHW_PRE(13) BHW_PRE(14) BHW_PRE(15) BHW_PRE(16) BHW_PRE(17) BHW_PRE(18) BHW_PRE(19)
+        BHW_PRE(20) BHW_PRE(21) BHW_PRE(22) BHW_PRE(23)
+#undef BHW_PRE
+        gx[threadIdx.x] = x; gy[threadIdx.x] = y; gz[threadIdx.x] = zf; gk[threadIdx.x] = k;
+    }
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t nmask = (1u << PW) - 1u;                                  // PW <= 32 here: a sweep of 2^PW phases in int32 indices
+    for (uint32_t gi = wave; gi < (uint32_t)kGroupsPerWg; gi += kBuildThreads / 64) {
+        const uint32_t g = group0 + gi;
+        if (g >= n_groups) break;
+        int64_t x = gx[gi], y = gy[gi];
+        int64_t z = gz[gi] + ((int64_t)lane << zs);
+        const int k0 = __builtin_amdgcn_readfirstlane(gk[gi]);
+#define BHW_POST(II) if constexpr (NITER > II) { if (II >= kmax || II >= k0) prerot_step<II>(x, y, z, c.lut[II], II + 1 == NITER); }
+        BHW_POST(0) BHW_POST(1) BHW_POST(2) BHW_POST(3) BHW_POST(4) BHW_POST(5) BHW_POST(6) BHW_POST(7)
+        BHW_POST(8) BHW_POST(9) BHW_POST(10) BHW_POST(11) BHW_POST(12) BHW_POST(13) BHW_POST(14) BHW_POST(15)
+        BHW_POST(16) BHW_POST(17) BHW_POST(18) BHW_POST(19) BHW_POST(20) BHW_POST(21) BHW_POST(22) BHW_POST(23)
+        BHW_POST(24) BHW_POST(25) BHW_POST(26) BHW_POST(27) BHW_POST(28) BHW_POST(29) BHW_POST(30) BHW_POST(31)
+#undef BHW_POST
+        const uint32_t i = ((g << 6) + lane - theta0) & nmask;
+        if (d_sin) d_sin[i] = (int32_t)(y >> (c.size - NITER));             // :257-258  top DATA_WIDTH bits
+        if (d_cos) d_cos[i] = (int32_t)(x >> (c.size - NITER));
+    }
+}
+
 // cordic_atan2 (src/cordic_atan2.vhd:126-213).  The B = ANGLE_WIDTH + PRECISION bit registers do wrap (PRECISION 1 with
 // full-scale inputs), so the state is kept shifted left by (word size - B): overflow of the word then *is* the B-bit wrap, and
 // the only extra work is clearing the low bits that an arithmetic right shift drags in.  U = uint32_t when B <= 32 (half the
@@ -2944,8 +3003,22 @@ int bhwk_sincos_prerot(const BhwLaunch &l, const BhwPrerotCfg &c, uint64_t theta
 {
     if (!count) return 0;
     BHW_SET_DEVICE(l);
-    const dim3 grid(grid_for(count)), block(kBlock);
     hipStream_t st = (hipStream_t)l.stream;
+    if (c.phi_width >= 16 && c.phi_width <= 30 && count == (1ull << c.phi_width)) {      // one whole period: shared rotation prefixes
+        const uint32_t groups = 1u << (c.phi_width - 6);
+        const dim3 grid((groups + kGroupsPerWg - 1) / kGroupsPerWg), block(kBuildThreads);
+        const uint32_t th0 = (uint32_t)(theta0 & ((1ull << c.phi_width) - 1ull));
+        switch (c.dat_width) {
+#define BHW_CASE(N) case N: BHW_LAUNCH(k_prerot_sweep<N>, grid, block, 0, st, c, th0, d_sin, d_cos); break;
+            BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14) BHW_CASE(15) BHW_CASE(16)
+            BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20) BHW_CASE(21) BHW_CASE(22) BHW_CASE(23) BHW_CASE(24)
+            BHW_CASE(25) BHW_CASE(26) BHW_CASE(27) BHW_CASE(28) BHW_CASE(29) BHW_CASE(30) BHW_CASE(31) BHW_CASE(32)
+#undef BHW_CASE
+        default: return (int)hipErrorInvalidValue;
+        }
+        return finish(hipSuccess);
+    }
+    const dim3 grid(grid_for(count)), block(kBlock);
     switch (c.dat_width) {                                              // DATA_WIDTH stages, unrolled
 #define BHW_CASE(N) case N: BHW_LAUNCH(k_sincos_prerot<N>, grid, block, 0, st, c, theta0, count, d_sin, d_cos); break;
         BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14) BHW_CASE(15) BHW_CASE(16)

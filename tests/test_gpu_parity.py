@@ -598,3 +598,18 @@ def test_whole_period_sincos_sweep_through_shared_prefixes(torch, model):
         assert np.array_equal(gs.cpu().numpy(), ws) and np.array_equal(gc.cpu().numpy(), wc), (model, pw, w, theta0)
         hs, hc = bhw.cordic(p, theta0, n + 1)                       # one more phase: the per-phase kernel
         assert bool((hs[:n] == gs).all()) and bool((hc[:n] == gc).all())
+
+
+@pytest.mark.parametrize("model", [B.MODEL_DDS48, B.MODEL_SCALED])
+def test_whole_period_sweep_of_the_variant_generators(torch, model):
+    """cordic_dds48 / cordic_dds_scaled over exactly one period (k_prerot_sweep: shared rotation prefixes per quadrant) against
+    the oracle, any start phase; one phase more takes the per-phase kernel and must give the same values."""
+    import blackman_harris_win_amd as bhw
+    for pw, w, theta0 in ((16, 16, 0), (18, 24, 54321), (20, 32, (1 << 20) - 3), (17, 8, 1 << 15), (22, 29, 7)):
+        p = B.make_params(1, pw, w, model=model)
+        n = 1 << pw
+        ws, wc = O.sincos_mt(O.from_bhw(p), theta0, n)
+        gs, gc = bhw.cordic(p, theta0, n)
+        assert np.array_equal(gs.cpu().numpy(), ws) and np.array_equal(gc.cpu().numpy(), wc), (model, pw, w, theta0)
+        hs, hc = bhw.cordic(p, theta0, n + 1)
+        assert bool((hs[:n] == gs).all()) and bool((hc[:n] == gc).all())
