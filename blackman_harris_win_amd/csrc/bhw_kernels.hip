@@ -980,8 +980,19 @@ __device__ __forceinline__ void tile_accumulate_uniform(uint32_t q, const int32_
 #undef BHW_UNI4
     }
 }
+// VHDL rule: the W+2-bit sums are carried as 4*hi + lo (Sum32), a term b adds b >> 2 to hi and b & 3 to lo -- the two halves of
+// the four candidates once, then the same scalar-branched accumulate for each half.
 template <int K, int OFF, int QBASE, int QBITS>
-__device__ __forceinline__ void tile_accumulate_uniform(uint32_t, const int32_t (&)[4], Sum32 (&)[4]) {}   // VHDL rule: never taken (see the call)
+__device__ __forceinline__ void tile_accumulate_uniform(uint32_t q, const int32_t (&sv)[4], Sum32 (&acc)[4])
+{
+    int32_t svh[4], svl[4], h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { svh[i] = sv[i] >> 2; svl[i] = sv[i] & 3; h[i] = acc[i].hi; l[i] = acc[i].lo; }
+    tile_accumulate_uniform<K, OFF, QBASE, QBITS>(q, svh, h);
+    tile_accumulate_uniform<K, OFF, QBASE, QBITS>(q, svl, l);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc[i].hi = h[i]; acc[i].lo = l[i]; }
+}
 
 // image j of a lane sits K*j quadrants after image 0; OFF = extra quadrants of this half-period image (even K: K/2)
 // UNSIGNED: the candidates come without the harmonic's sign (tile_harmonic FAST): odd harmonics are subtracted
@@ -1274,7 +1285,7 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
             int32_t sv[4];                                                                               \
             /* only quadrant bits 0,1 of theta >> lq are used */                                         \
             const int32_t aK = FAST ? (int32_t)((uint32_t)win.aa[K] << (34u - W)) : win.aa[K];          \
-            if constexpr (LDS && BHW_TILE_UNIQ && FAST && MODE != 2) {                                   \
+            if constexpr (LDS && BHW_TILE_UNIQ && (FAST || MODE == 2)) {                                 \
                 /* no run of this tile crosses a quarter turn: the quadrants are scalars (qpack) */      \
                 tile_harmonic<K, MODE, 0, 0, FAST>(cfg, aK, W, cs[b][0], 0u, sv);                        \
                 const uint32_t q0 = (qpack[b] >> (2 * rec_set_index(K, 0))) & 3u;                        \
