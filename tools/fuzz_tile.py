@@ -12,11 +12,13 @@ import blackman_harris_win_amd as bhw
 from blackman_harris_win_amd import binding as B
 
 
-def fuzz(budget=60.0, seed=1, max_cases=None, pws=(22, 22, 23, 23, 24, 24, 25, 26)):
+def fuzz(budget=60.0, seed=1, max_cases=None, pws=(22, 22, 23, 23, 24, 24, 25, 26), verbose=False):
     """Runs until `budget` seconds or `max_cases` cases; returns (cases, coefficients, plans); raises AssertionError on a mismatch."""
     rng = np.random.default_rng(seed)
-    t0 = time.time(); cases = 0; samples = 0; plans = {}
+    t0 = time.time(); cases = 0; samples = 0; plans = {}; last = t0
     while (budget is None or time.time() - t0 < budget) and (max_cases is None or cases < max_cases):
+        if verbose and time.time() - last > 60:                          # progress line (long silent runs are taken to be hung)
+            last = time.time(); print("... %d cases, %d coefficients so far" % (cases, samples), flush=True)
         win = int(rng.choice([1, 2, 3, 4, 5, 7])); model = int(rng.integers(0, 3)); combine = int(rng.integers(0, 2))
         pw = int(rng.choice(pws)); w = int(rng.integers(8, 33))
         if model == B.MODEL_HLS and pw > w + 2:
@@ -60,7 +62,7 @@ def fuzz(budget=60.0, seed=1, max_cases=None, pws=(22, 22, 23, 23, 24, 24, 25, 2
 
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-    cases, samples, plans = fuzz(budget, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    cases, samples, plans = fuzz(budget, int(sys.argv[2]) if len(sys.argv) > 2 else 1, verbose=True)
     print("tile fuzz: %d cases, %d coefficients, all bit-exact; plans %s" % (cases, samples, plans))
 
 
