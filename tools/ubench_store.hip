@@ -63,7 +63,7 @@ int main()
         printf("%-64s %8.4f ms  %7.1f GB/s\n", name, ms, n * 4 / (ms * 1e-3) / 1e9);
     };
     const unsigned tiles = (unsigned)(H / 2880u) + 1u;           // 15 runs x 192 lanes per tile (the last tile overlaps)
-    report("tile pattern, block order (14564 x 960 threads)", [&]() { hipLaunchKernelGGL(k_store<0>, dim3(tiles), dim3(960), 0, 0, buf, 1); });
+    report("tile pattern, block order (2913 x 960 threads)", [&]() { hipLaunchKernelGGL(k_store<0>, dim3(tiles), dim3(960), 0, 0, buf, 1); });
     report("tile pattern, XCD-aware tile order", [&]() { hipLaunchKernelGGL(k_store<1>, dim3(tiles), dim3(960), 0, 0, buf, 1); });
     report("streaming dwordx4, 65536 x 256 threads", [&]() { hipLaunchKernelGGL(k_stream, dim3(65536), dim3(256), 0, 0, (int4 *)buf, n / 4, 1); });
     report("streaming dword per lane, 65536 x 256 threads, grid-stride", [&]() { hipLaunchKernelGGL(k_stream1, dim3(65536), dim3(256), 0, 0, buf, n, 1); });
