@@ -511,7 +511,13 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
     // ragged ends the general gather kernel
     const uint64_t N = 1ull << p->phi_width;
     const bool has_period = count >= (N - n0 % N) % N + N;
-    const bool tiled = has_period && bhwk_tile_applicable(c, w);
+    // a contiguous range of whole eighths of one window (one device's contiguous shard of a window split over 2, 4 or 8): the
+    // tile kernel over the images it covers
+    uint32_t img_mask = 0xFFu, n0mod = 0u;
+    BhwWinCfg w_probe = w;
+    w_probe.apply_x = apply_x;
+    const bool images = !has_period && bhwk_tile_images_applicable(c, w_probe, n0, count, &img_mask, &n0mod);
+    const bool tiled = (has_period && bhwk_tile_applicable(c, w)) || images;
     c.tab_split = (tiled && c.z_shr == 0) ? 1u : 0u;
     // whole-period tile tables are stored packed when the widths allow it (formats in bhw_kernels.hip): "residual" = 2 bytes per
     // entry + one int4 record per 2^d entries, else "delta16" = 4 bytes per entry + one int2 head per 64 entries, else the plain
@@ -533,6 +539,10 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
         return tiled ? bhwk_table_combine_tile(l, c, w, (const int32_t *)ws, d_out + off)
                      : bhwk_table_combine_fold(l, c, w, (const int32_t *)ws, d_out + off);
     };
+    if (images) {
+        const int e = bhwk_table_combine_tile_range(l, c, w, (const int32_t *)ws, d_out, 0, 0, img_mask, n0mod);
+        return e ? fail_hip(e, "tile launch (image subset)") : BHW_OK;
+    }
     return run_split(l, n0, count, N, apply_x != nullptr, d_out, ragged, period);
 }
 
@@ -667,7 +677,9 @@ int bhw_describe_plan(const bhw_params *p, uint64_t n0, uint64_t count, const bh
                  (w.combine != BHW_COMBINE_HLS) ? 2 : (c.ones_neg ? 1 : 0));
         return BHW_OK;
     }
-    const bool tiled = period && bhwk_tile_applicable(c, w);
+    uint32_t img_mask = 0xFFu, n0mod = 0u;
+    const bool images = !period && bhwk_tile_images_applicable(c, w, n0, count, &img_mask, &n0mod);
+    const bool tiled = (period && bhwk_tile_applicable(c, w)) || images;
     c.tab_split = (tiled && c.z_shr == 0) ? 1u : 0u;
     uint32_t cand[kMaxFormats];
     const int n_cand = table_format_candidates(c, tiled, exec_table_format(ex), cand);
@@ -683,8 +695,8 @@ int bhw_describe_plan(const bhw_params *p, uint64_t n0, uint64_t count, const bh
     char build[64], combine[64];
     bhwk_describe_table(c, w, tiled, build, combine, sizeof build);
     const char *fmt = c.tab_dlog == 0 ? "plain" : c.tab_dlog == 6 ? "delta16" : c.tab_dlog >= 16 ? "nibble" : "residual";
-    snprintf(buf, len, "table[%s%s]: %s + %s%s", fmt, state, build, period ? combine : "k_table_combine",
-             period && count != (1ull << p->phi_width) ? " (+ k_table_combine / k_replicate on the rest)" : "");
+    snprintf(buf, len, "table[%s%s]: %s + %s%s", fmt, state, build, (period || images) ? combine : "k_table_combine",
+             images ? " (image subset)" : period && count != (1ull << p->phi_width) ? " (+ k_table_combine / k_replicate on the rest)" : "");
     return BHW_OK;
 }
 

@@ -90,7 +90,8 @@ bool bhwk_tile_applicable(const BhwCordicCfg &c, const BhwWinCfg &w);
 void bhwk_describe_table(const BhwCordicCfg &c, const BhwWinCfg &w, bool tiled, char *build, char *combine, size_t len);
 // tiles [tile0, tile0 + tile_count) of the tile plan only (tile_count 0: the whole ring)
 int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out,
-                                  uint32_t tile0, uint32_t tile_count);
+                                  uint32_t tile0, uint32_t tile_count, uint32_t img_mask = 0xFFu, uint32_t n0mod = 0u);
+bool bhwk_tile_images_applicable(const BhwCordicCfg &c, const BhwWinCfg &w, uint64_t n0, uint64_t count, uint32_t *img_mask, uint32_t *n0mod);
 // Run-length kernel: whole period of a configuration that drops phase bits (z_shr > 0), over the plain natural table
 bool bhwk_runlength_applicable(const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_out);
 int bhwk_runlength_window(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out);

@@ -778,6 +778,8 @@ struct BhwTilePlan {
     uint32_t offs[16];   // (i3*inv3 + i5*inv5) mod ring, index i3 + 3*i5; padded by repeating the last run
     uint32_t n_tiles;    // tiles that cover the ring once
     uint32_t tile0;      // first tile of this launch (interleaved ownership parts launch a sub-range of the tiles)
+    uint32_t img_mask;   // MASKED instances: bit 2j + h set = image (h, j), i.e. stream indices [(2j + h) N/8, +N/8), is wanted
+    uint32_t n0mod;      // MASKED instances: stream index (mod N) that `out` points at; image m lands at ((m N/8 - n0mod) mod N)
 };
 
 __device__ __forceinline__ int32_t wrap32(int32_t v, uint32_t bits)
@@ -1123,7 +1125,10 @@ __host__ __device__ constexpr int gather_order(int K, int b, int g)     // consu
 // Lane r in [0, E/2) owns the eight coefficients n = r + h*E/2 + j*E (h = 0,1; j = 0..3).  For even k the
 // two h-images share one gather (k*E/2 is a whole number of quadrants); for odd k the second image reads
 // entry t + E/2, another dense span of the same tile.
-template <int NB, int MODE, int FMT, bool FAST = false>
+// MASKED: the launch produces only some of the eight images (a contiguous index range of the window that is a whole number of
+// eighths -- one device's contiguous shard of a window split over 2, 4 or 8): a gather is skipped when no wanted image reads it
+// (odd harmonics: the h = 0 / h = 1 gathers), sums of an unwanted half are not formed, unwanted images are not stored.
+template <int NB, int MODE, int FMT, bool FAST = false, bool MASKED = false>
 __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 4 : BHW_TILE_WAVES))) void k_table_combine_tile(BhwCordicCfg cfg, BhwWinCfg win, BhwTilePlan tp,
                                                                       const void *__restrict__ table, int32_t *__restrict__ out)
 {
@@ -1174,6 +1179,8 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
     for (int b = 0; b < NR; ++b) cls[b] = split_class<FMT>(rr[b], lq);
     constexpr bool kPrefetch = BHW_TILE_PREFETCH && kLdsRec && NR == 3;
     uint32_t land[kPrefetch ? 27 : 1];                               // residual words, one per gather (gather_order)
+    // MASKED: which half-period images (h = 0: even image numbers, h = 1: odd) this launch wants at all
+    const bool want0 = !MASKED || (tp.img_mask & 0x55u) != 0u, want1 = !MASKED || (tp.img_mask & 0xAAu) != 0u;
     auto issue_runs = [&](auto run_tag) {
         constexpr int B0 = decltype(run_tag)::value < 0 ? 0 : decltype(run_tag)::value, B1 = decltype(run_tag)::value < 0 ? NR : B0 + 1;
 #define BHW_TILE_ISSUE(K)                                                                                \
@@ -1182,6 +1189,7 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
             constexpr int KC = (K % 4 == 0) ? 4 : (K % 2 == 0) ? 2 : 0;                                  \
             _Pragma("unroll") for (int b = B0; b < B1; ++b) {                                            \
                 _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                         \
+                    if (MASKED && NG == 2 && !(g ? want1 : want0)) continue;                             \
                     const uint32_t u = ((uint32_t)K * (rr[b] + (uint32_t)g * H)) & emask;                \
                     const uint32_t idx2 = (K & 1) ? ((u >> (cls[b] & 31u)) | cls[b]) & ~1u : tab_index<KC, 1>(u, lq, 1u) << 1; \
                     land[gather_order(K, b, g)] = FMT == 3 ? (uint32_t)ld_off<uint8_t>(table, idx2 >> 1) : (uint32_t)ld_off<uint16_t>(table, idx2); \
@@ -1270,6 +1278,7 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
         int2 cs[NR][NG];                                                                                 \
         _Pragma("unroll") for (int b = B0; b < B1; ++b) {                                                 \
             _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                             \
+                if (MASKED && NG == 2 && !(g ? want1 : want0)) continue;                                 \
                 const uint32_t theta = (uint32_t)K * (rr[b] + (uint32_t)g * H);                          \
                 const uint32_t bias = rbias[rec_set_index(K, g)][b];                                     \
                 if constexpr (kPrefetch && LDS) {                                                        \
@@ -1287,25 +1296,32 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
             const int32_t aK = FAST ? (int32_t)((uint32_t)win.aa[K] << (34u - W)) : win.aa[K];          \
             if constexpr (LDS && BHW_TILE_UNIQ && (FAST || MODE == 2)) {                                 \
                 /* no run of this tile crosses a quarter turn: the quadrants are scalars (qpack) */      \
-                tile_harmonic<K, MODE, 0, 0, FAST>(cfg, aK, W, cs[b][0], 0u, sv);                        \
                 const uint32_t q0 = (qpack[b] >> (2 * rec_set_index(K, 0))) & 3u;                        \
-                tile_accumulate_uniform<K, 0, ring_qbase(K, 0), ring_qbits(K, 0)>(q0, sv, acc[b][0]);    \
-                if constexpr (NG == 1) tile_accumulate_uniform<K, K / 2, ring_qbase(K, 0), ring_qbits(K, 0)>(q0, sv, acc[b][1]); \
-                else {                                                                                   \
+                if (NG == 1 || want0) {                                                                  \
+                    tile_harmonic<K, MODE, 0, 0, FAST>(cfg, aK, W, cs[b][0], 0u, sv);                    \
+                    if (want0) tile_accumulate_uniform<K, 0, ring_qbase(K, 0), ring_qbits(K, 0)>(q0, sv, acc[b][0]); \
+                }                                                                                        \
+                if constexpr (NG == 1) {                                                                 \
+                    if (want1) tile_accumulate_uniform<K, K / 2, ring_qbase(K, 0), ring_qbits(K, 0)>(q0, sv, acc[b][1]); \
+                } else if (want1) {                                                                      \
                     tile_harmonic<K, MODE, 0, 0, FAST>(cfg, aK, W, cs[b][1], 0u, sv);                    \
                     const uint32_t q1 = (qpack[b] >> (2 * rec_set_index(K, 1))) & 3u;                    \
                     tile_accumulate_uniform<K, 0, ring_qbase(K, 1), ring_qbits(K, 1)>(q1, sv, acc[b][1]); \
                 }                                                                                        \
                 continue;                                                                                \
             }                                                                                            \
-            tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0), FAST>(cfg, aK, W, cs[b][0], ((uint32_t)K * rr[b]) >> lq_v, sv); \
-            tile_accumulate<K, 0, FAST>(sv, acc[b][0]);                                                        \
+            if (NG == 1 || want0) {                                                                      \
+                tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0), FAST>(cfg, aK, W, cs[b][0], ((uint32_t)K * rr[b]) >> lq_v, sv); \
+                if (want0) tile_accumulate<K, 0, FAST>(sv, acc[b][0]);                                         \
+            }                                                                                            \
             if constexpr (NG == 2) {                                                                     \
-                tile_harmonic<K, MODE, ring_qbase(K, 1), ring_qbits(K, 1), FAST>(cfg, aK, W, cs[b][NG - 1], ((uint32_t)K * (rr[b] + H)) >> lq_v, sv); \
-                tile_accumulate<K, 0, FAST>(sv, acc[b][1]);                                                    \
+                if (want1) {                                                                             \
+                    tile_harmonic<K, MODE, ring_qbase(K, 1), ring_qbits(K, 1), FAST>(cfg, aK, W, cs[b][NG - 1], ((uint32_t)K * (rr[b] + H)) >> lq_v, sv); \
+                    tile_accumulate<K, 0, FAST>(sv, acc[b][1]);                                                \
+                }                                                                                        \
             } else {                                                                                     \
                 /* even K: the second half-period image reads the same entry K/2 quadrants further on */ \
-                tile_accumulate<K, K / 2, FAST>(sv, acc[b][1]);                                                \
+                if (want1) tile_accumulate<K, K / 2, FAST>(sv, acc[b][1]);                                     \
             }                                                                                            \
         }                                                                                                \
     }
@@ -1338,7 +1354,9 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+                    if (MASKED && !((tp.img_mask >> (2 * j + h)) & 1u)) continue;
                     uint64_t img_off = (uint64_t)h * H + (uint64_t)j * E;
+                    if (MASKED) img_off = (img_off - tp.n0mod) & (4ull * E - 1ull);      // position of the image in the caller's range
                     asm volatile("" : "+s"(img_off));
                     int32_t *img = out + img_off;
 #pragma unroll
@@ -2555,7 +2573,7 @@ static void make_tile_plan(const BhwCordicCfg &c, const BhwWinCfg &w, BhwTilePla
 
 // Tiles [tile0, tile0 + tile_count) of the plan (tile_count 0: all of them).
 int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out,
-                                  uint32_t tile0, uint32_t tile_count)
+                                  uint32_t tile0, uint32_t tile_count, uint32_t img_mask, uint32_t n0mod)
 {
     BHW_SET_DEVICE(l);
     hipStream_t st = (hipStream_t)l.stream;
@@ -2566,6 +2584,10 @@ int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c, con
     if (tile_count == 0) { tile0 = 0; tile_count = tp.n_tiles; }
     if (tile0 + tile_count > tp.n_tiles) return (int)hipErrorInvalidValue;
     tp.tile0 = tile0;
+    tp.img_mask = img_mask & 0xFFu;
+    tp.n0mod = n0mod;
+    const bool masked = tp.img_mask != 0xFFu;                       // some of the eight images only (bhwk_tile_images_applicable)
+    if (masked && (nb != 15 || w.apply_x != nullptr || tp.img_mask == 0u)) return (int)hipErrorInvalidValue;
     const int mode = (w.combine != BHW_COMBINE_HLS) ? 2 : (c.ones_neg ? 1 : 0);
     const dim3 grid(tile_count), block(kTileThreads);
     // one-instruction products (tile_harmonic FAST): HLS rule, 15-run tiles, every harmonic weight below 2^(W-3) in magnitude
@@ -2578,12 +2600,17 @@ int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c, con
         const int64_t lim = (int64_t)1 << (c.dat_width - 3);
         fast = (int64_t)w.aa[k] < lim && (int64_t)w.aa[k] >= -lim;
     }
+#define BHW_LAUNCH_TILE_MFK(NB, M, F, K)                                                                                 \
+    do {                                                                                                                 \
+        if (c.tab_dlog == 0)             BHW_LAUNCH((k_table_combine_tile<NB, M, 0, F, K>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
+        else if (c.tab_dlog == kPackLog) BHW_LAUNCH((k_table_combine_tile<NB, M, 1, F, K>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
+        else if (c.tab_dlog < kNibbleFlag) BHW_LAUNCH((k_table_combine_tile<NB, M, 2, F, K>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
+        else                             BHW_LAUNCH((k_table_combine_tile<NB, M, 3, F, K>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
+    } while (0)
 #define BHW_LAUNCH_TILE_MF(NB, M, F)                                                                                     \
     do {                                                                                                                 \
-        if (c.tab_dlog == 0)             BHW_LAUNCH((k_table_combine_tile<NB, M, 0, F>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
-        else if (c.tab_dlog == kPackLog) BHW_LAUNCH((k_table_combine_tile<NB, M, 1, F>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
-        else if (c.tab_dlog < kNibbleFlag) BHW_LAUNCH((k_table_combine_tile<NB, M, 2, F>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
-        else                             BHW_LAUNCH((k_table_combine_tile<NB, M, 3, F>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
+        if (NB == 15 && masked) BHW_LAUNCH_TILE_MFK(NB, M, F, (NB == 15));                                               \
+        else                    BHW_LAUNCH_TILE_MFK(NB, M, F, false);                                                    \
     } while (0)
 #define BHW_LAUNCH_TILE_M(NB, M)                                                                                         \
     do {                                                                                                                 \
@@ -2601,13 +2628,29 @@ int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c, con
     else BHW_LAUNCH_TILE(1);
 #undef BHW_LAUNCH_TILE_M
 #undef BHW_LAUNCH_TILE_MF
+#undef BHW_LAUNCH_TILE_MFK
 #undef BHW_LAUNCH_TILE
     return finish(hipSuccess);
 }
 
 int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out)
 {
-    return bhwk_table_combine_tile_range(l, c, w, d_table, d_out, 0, 0);
+    return bhwk_table_combine_tile_range(l, c, w, d_table, d_out, 0, 0, 0xFFu, 0u);
+}
+
+// A contiguous index range that is a whole number of eighths of the window (and less than all of it) can be produced by the
+// tile kernel as a subset of its eight images: `*img_mask` = the images, `*n0mod` = n0 mod N (see BhwTilePlan).
+bool bhwk_tile_images_applicable(const BhwCordicCfg &c, const BhwWinCfg &w, uint64_t n0, uint64_t count, uint32_t *img_mask, uint32_t *n0mod)
+{
+    if (!bhwk_tile_applicable(c, w) || c.z_shr != 0 || w.apply_x != nullptr || w.n_terms <= 5) return false;   // 15-run tiles only
+    const uint64_t N = 1ull << c.phi_width, eighth = N >> 3;
+    if (count == 0 || count >= N || (count % eighth) != 0 || (n0 % eighth) != 0) return false;
+    const uint32_t m0 = (uint32_t)((n0 % N) / eighth), n_img = (uint32_t)(count / eighth);
+    uint32_t mask = 0;
+    for (uint32_t i = 0; i < n_img; ++i) mask |= 1u << ((m0 + i) & 7u);
+    *img_mask = mask;
+    *n0mod = (uint32_t)(n0 % N);
+    return true;
 }
 
 // Kernel names of the table strategy's two passes for a resolved configuration (bhw_describe_plan: profilers, bench labels).

@@ -155,12 +155,12 @@ def test_headline_kernels_have_no_scratch():
         _build.build_library(force=True)
     with open(_build.RESOURCES) as f:
         res = json.load(f)
-    headline = ["k_table_build_shared<32, 3>", "k_table_build_shared<32, 2>", "k_table_combine_tile<15, 0, 3, true>",
-                "k_table_combine_tile<15, 0, 2, true>", "k_table_combine_tile<15, 1, 2, true>", "k_table_combine_tile<15, 0, 2, false>",
+    headline = ["k_table_build_shared<32, 3>", "k_table_build_shared<32, 2>", "k_table_combine_tile<15, 0, 3, true, false>",
+                "k_table_combine_tile<15, 0, 2, true, false>", "k_table_combine_tile<15, 1, 2, true, false>", "k_table_combine_tile<15, 0, 2, false, false>",
                 "k_fold_direct<7, 0, false>", "k_fold_direct<4, 0, true>", "k_fold_split<4, 0>", "k_runlength_window<7, 1, true>"]
     for name in headline:
         assert name in res, name
     for name, r in res.items():                                      # no kernel of the library uses scratch
         assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0, (name, r)
-    for name in ("k_table_combine_tile<15, 0, 3, true>", "k_table_combine_tile<15, 0, 2, true>"):
+    for name in ("k_table_combine_tile<15, 0, 3, true, false>", "k_table_combine_tile<15, 0, 2, true, false>"):
         assert res[name]["VGPRs"] <= 64 and res[name]["LDS Size"] <= 80 * 1024, (name, res[name])   # two 960-thread workgroups per CU

@@ -230,3 +230,25 @@ def test_runlength_kernel_matches_direct_and_oracle(win, pw, w, model, combine, 
         assert bool((two[777:777 + n] == got).all()) and bool((two[777 + n:777 + 2 * n] == got).all())
         assert bool((two[:777] == got[-777:]).all()) and bool((two[777 + 2 * n:] == got[:723]).all())
     del got, ref
+
+
+@pytest.mark.gpu
+def test_contiguous_eighth_ranges_take_the_tile_kernel():
+    """A contiguous range of whole eighths of a window (a device's contiguous shard of a window split over 2, 4 or 8) is produced
+    by the tile kernel over the images it covers: every (first eighth, number of eighths) pair, ranges that run past the end of
+    the period included, against the whole window; the plan says so."""
+    import torch
+    import blackman_harris_win_amd as bhw
+    for win, pw, w, model, combine in ((7, 22, 32, B.MODEL_HLS, B.COMBINE_HLS), (7, 23, 30, B.MODEL_CPP, B.COMBINE_HLS),
+                                       (7, 22, 24, B.MODEL_VHDL, B.COMBINE_VHDL)):
+        p = B.make_params(win, pw, w, model=model, combine=combine)
+        n = 1 << pw
+        e = n >> 3
+        full = torch.from_numpy(O.generate_mt(O.from_bhw(p), 0, n)).cuda()
+        two = torch.cat([full, full])
+        for m0 in range(8):
+            for k in range(1, 8):
+                got = bhw.generate(p, 5 * n + m0 * e, k * e, algo=B.ALGO_TABLE)
+                assert bool((got == two[m0 * e:(m0 + k) * e]).all()), (win, pw, w, model, m0, k)
+        assert "image subset" in B.describe_plan(p, 3 * e, 2 * e, algo=B.ALGO_TABLE)
+        assert "image subset" not in B.describe_plan(p, 3 * e + 1, 2 * e, algo=B.ALGO_TABLE)
