@@ -252,3 +252,16 @@ def test_contiguous_eighth_ranges_take_the_tile_kernel():
                 assert bool((got == two[m0 * e:(m0 + k) * e]).all()), (win, pw, w, model, m0, k)
         assert "image subset" in B.describe_plan(p, 3 * e, 2 * e, algo=B.ALGO_TABLE)
         assert "image subset" not in B.describe_plan(p, 3 * e + 1, 2 * e, algo=B.ALGO_TABLE)
+
+
+def test_plan_of_contiguous_eighth_ranges_on_the_host():
+    """bhw_describe_plan (host arithmetic only): which contiguous ranges take the tile kernel with an image mask."""
+    p = B.make_params(7, 26, 32)
+    e = 1 << 23
+    for n0, count, want in ((0, e, True), (3 * e, 2 * e, True), (7 * e, 3 * e, True), (5 * (1 << 26) + e, 6 * e, True),
+                            (0, 8 * e, False), (1, e, False), (0, e + 1, False), (e // 2, e, False), (0, 9 * e, False)):
+        assert ("image subset" in B.describe_plan(p, n0, count, algo=B.ALGO_TABLE)) == want, (n0, count)
+    # fewer than seven terms (3-run tiles), short windows and dropped phase bits keep the general gather kernel
+    for q in (B.make_params(4, 26, 24), B.make_params(7, 20, 32), B.make_params(7, 26, 16, model=B.MODEL_CPP)):
+        n = 1 << q.phi_width
+        assert "image subset" not in B.describe_plan(q, 0, n >> 3, algo=B.ALGO_TABLE)
