@@ -413,6 +413,10 @@ __global__ __launch_bounds__(kBlock) void k_table_build(BhwCordicCfg cfg, uint32
 // Valid when |x|,|y| < 2^33 and the quarter circle <= 2^32 (all models at W <= 32; VHDL: W+P <= 34):
 // rotation 0 always adds (z0 >= 0), giving x1 = y1 = x0 and z1 = z0 - lut[0], which fits int32.
 // ---------------------------------------------------------------------------------------
+#ifndef BHW_HEADS_UNROLL
+#define BHW_HEADS_UNROLL 1     // the cell-head chains unrolled on scalar ROM words: every workgroup starts with them (and the group prefixes), and a
+                              // rolled loop on the LDS copy of the ROM makes that start 120 instructions longer: 0.1468 -> 0.1451 ms per window
+#endif
 #ifndef BHW_PREFIX_MAX
 #define BHW_PREFIX_MAX 20
 #endif
@@ -494,8 +498,13 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
         if (cell >= 0 && cell < (int64_t)cells_total) {
             int64_t x = plan.x0, y = plan.x0;
             int32_t z = (int32_t)((((uint32_t)cell << d) << s) - lut_s[0]);
+#if BHW_HEADS_UNROLL
+#pragma unroll
+            for (int r = 1; r < n_iter; ++r) rot_step(x, y, z, r, plan.lut[r]);
+#else
 #pragma unroll 1
             for (int r = 1; r < n_iter; ++r) rot_step(x, y, z, r, lut_s[r]);
+#endif
             hc[t] = (int32_t)(x >> plan.out_shr);
             hs[t] = (int32_t)(y >> plan.out_shr);
         }
@@ -607,6 +616,238 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
                 reinterpret_cast<uint16_t *>(table)[idx] = (uint16_t)(((uint32_t)dc & 0xFFu) | (((uint32_t)ds & 0xFFu) << 8));
             }
         }
+    }
+}
+
+// Table strategy, pass 1, octant-mirror form (residual / nibble formats in the split layout; BHW_BUILD_MIRROR).
+//
+// After rotation 0 the state is the 45-degree vector (x0, x0) and 2 * lut[0] is exactly a quarter turn (checked by the launcher),
+// so the chain of u' = E - u is the chain of u with x and y swapped, z negated and every decision flipped -- bit for bit, floors
+// included -- as long as no z_k on the way is exactly 0 (z >= 0 rotates forward in both).  Zero events are common only in the last
+// rotations (|z| is a few units there), so:
+//   * only u in [0, E/2 + 64) run a chain of their own; u' in [E/2 + 64, E) are images of u in [1, E/2 - 64];
+//   * at rotation KS = NITER - BHW_MIRROR_TAIL the image state is taken as (y, x, -z) and the last rotations run for both;
+//   * a lane that met z_k == 0 before KS (one v_cmp per shared rotation, collected in a scalar mask; about 1 % of the lanes, but
+//     every second wave has one) does not store its image: it appends u to a worklist in shared memory, and after the groups
+//     the workgroup's first lanes run those images as chains of their own (a wave-wide replay in place costs more than the
+//     symmetry saves);
+//   * a group whose shared prefix itself met z == 0 (only its leaf 0 can) recomputes that one image from scratch;
+//   * the records of the image cells come from chains of their own (third wave), never from the symmetry.
+// Per pair of entries 9 shared + 2 x 6 own rotations instead of 2 x 15.
+#ifndef BHW_MIRROR_TAIL
+#define BHW_MIRROR_TAIL 6
+#endif
+#ifndef BHW_MIRROR_GPW
+#define BHW_MIRROR_GPW 64
+#endif
+template <int NITER, int FMT>
+__global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPlan plan, void *__restrict__ table)
+{
+    static_assert(FMT == 2 || FMT == 3, "residual / nibble entries");
+    __shared__ int64_t gx[kGroupsPerWg];
+    __shared__ int64_t gy[kGroupsPerWg];
+    __shared__ int32_t gz[kGroupsPerWg];
+    __shared__ int32_t gk[kGroupsPerWg];
+    __shared__ uint32_t gflag[kGroupsPerWg];
+    __shared__ uint32_t lut_s[32];
+    constexpr uint32_t kWorkMax = 512;                               // images to run as chains of their own (expected ~40 per workgroup)
+    __shared__ uint32_t work_n;
+    __shared__ uint32_t work_u[kWorkMax];
+    if (threadIdx.x < 32) lut_s[threadIdx.x] = plan.lut[threadIdx.x];
+    if (threadIdx.x == 0) work_n = 0u;
+    __syncthreads();
+
+    constexpr int n_iter = NITER;
+    constexpr int KS = NITER - BHW_MIRROR_TAIL;                      // image state taken at this rotation
+    const uint32_t s = plan.z_shl;
+    constexpr uint32_t gpw = BHW_MIRROR_GPW;                         // own groups per workgroup
+    const uint32_t group0 = blockIdx.x * gpw;
+    const uint32_t E = plan.entries;
+    const uint32_t n_groups = (E >> 7) + 1u;                         // groups that run chains of their own
+    const uint32_t u_lo = group0 << 6;
+    const uint32_t u_hi = ((group0 + gpw) << 6) < (n_groups << 6) ? ((group0 + gpw) << 6) : (n_groups << 6);   // own entries [u_lo, u_hi)
+    const uint32_t m_last = (E >> 1) - 64u;                          // u in [1, m_last] also produce the image E - u
+
+    // records {c, s, dc, ds} of the cells this workgroup stores into: w = 0 its own range, w = 1 the image range.  Heads
+    // lo .. lo + n, plus head lo - 1 for the table's last cell (see k_table_build_shared), by full chains of the second / third wave.
+    __shared__ int32_t hc[2][kHeadsMax], hs[2][kHeadsMax];
+    const uint32_t d = fmt_cell_log(plan.tab_dlog);
+    const uint32_t cells_total = E >> d;
+    uint32_t cell_lo[2] = {0u, 0u}, n_cell[2] = {0u, 0u}, r_lo[2] = {u_lo, 0u}, r_hi[2] = {u_hi, 0u};   // entry ranges [r_lo, r_hi)
+    {
+        const uint32_t a = u_lo > 1u ? u_lo : 1u, b = (u_hi - 1u) < m_last ? (u_hi - 1u) : m_last;        // sources a .. b
+        if (a <= b) { r_lo[1] = E - b; r_hi[1] = E - a + 1u; }
+    }
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+        if (r_hi[w] > r_lo[w]) {
+            cell_lo[w] = r_lo[w] >> d;
+            n_cell[w] = ((r_hi[w] - 1u) >> d) - cell_lo[w] + 1u;
+        }
+    {
+        const uint32_t w = (threadIdx.x >> 6) - 1u;                  // wave 1 -> own range, wave 2 -> image range
+        const uint32_t t = threadIdx.x & 63u;
+        if (w < 2u && n_cell[w] && t < n_cell[w] + 2u) {
+            const int64_t cell = (t <= n_cell[w]) ? (int64_t)cell_lo[w] + t : (int64_t)cell_lo[w] - 1;
+            if (cell >= 0 && cell < (int64_t)cells_total) {
+                int64_t x = plan.x0, y = plan.x0;
+                int32_t z = (int32_t)((((uint32_t)cell << d) << s) - lut_s[0]);
+#if BHW_HEADS_UNROLL
+#pragma unroll
+                for (int r = 1; r < n_iter; ++r) rot_step(x, y, z, r, plan.lut[r]);
+#else
+#pragma unroll 1
+                for (int r = 1; r < n_iter; ++r) rot_step(x, y, z, r, lut_s[r]);
+#endif
+                hc[w][t] = (int32_t)(x >> plan.out_shr);
+                hs[w][t] = (int32_t)(y >> plan.out_shr);
+            }
+        }
+    }
+
+    // ---- phase 1: shared prefix of each 64-leaf group (never past KS: the image state is taken there) ----
+    constexpr int kcap = KS < kPrefixMax ? KS : kPrefixMax;
+    if (threadIdx.x < gpw) {
+        const uint32_t g = group0 + threadIdx.x;
+        const uint32_t u_first = g << 6;
+        int64_t x = plan.x0, y = plan.x0;                                        // after rotation 0
+        int32_t zf = (int32_t)((u_first << s) - lut_s[0]);
+        const uint32_t span = 63u << s;                                          // z_last - z_first
+        int k = 1;
+        bool live = g < n_groups;
+        uint32_t zero0 = 0u;                                                     // leaf 0 met z == 0 inside the shared prefix
+#pragma unroll
+        for (int kk = 1; kk < kcap; ++kk) {
+            if (live) {
+                const int32_t zl = (int32_t)((uint32_t)zf + span);
+                if ((zf < 0) != (zl < 0)) {
+                    live = false;                                                // the group splits at rotation kk
+                } else {
+                    zero0 |= (uint32_t)(zf == 0);
+                    rot_step(x, y, zf, kk, plan.lut[kk]);
+                    k = kk + 1;
+                }
+            }
+        }
+        gx[threadIdx.x] = x;
+        gy[threadIdx.x] = y;
+        gz[threadIdx.x] = zf;
+        gk[threadIdx.x] = k;
+        gflag[threadIdx.x] = zero0;
+    }
+    __syncthreads();
+
+    auto record_of = [&](int w, uint32_t cell) -> int4 {           // cell in [cell_lo[w], cell_lo[w] + n_cell[w])
+        const uint32_t t = cell - cell_lo[w];
+        if (cell + 1u < cells_total) return make_int4(hc[w][t], hs[w][t], hc[w][t + 1] - hc[w][t], hs[w][t + 1] - hs[w][t]);
+        const uint32_t tp = t ? t - 1u : n_cell[w] + 1u;             // last cell of the table: slope of the cell before it
+        return make_int4(hc[w][t], hs[w][t], hc[w][t] - hc[w][tp], hs[w][t] - hs[w][tp]);
+    };
+    auto record = [&](int w, uint32_t cell) -> int4 {              // the same for a wave-uniform cell (scalar control flow)
+        return record_of(w, __builtin_amdgcn_readfirstlane(cell));
+    };
+    {
+        const uint32_t w = threadIdx.x >> 6, t = threadIdx.x & 63u;
+        if (w < 2u && t < n_cell[w]) {
+            const uint32_t cell = cell_lo[w] + t;
+            if ((cell << d) >= r_lo[w])                              // its first entry is stored by this workgroup
+                reinterpret_cast<int4 *>(const_cast<void *>(plan.tab_coarse))[cell] = record_of((int)w, cell);
+        }
+    }
+
+    // one entry: deviation from the record's straight line, checked and packed
+    auto store_entry = [&](uint32_t idx, int32_t c, int32_t sn, const int4 rec, uint32_t pos) {
+        const int2 p = tab_predict(rec, pos, d);
+        const int32_t dc = c - p.x, ds = sn - p.y;
+        if constexpr (FMT == 3) {
+            if (plan.check_flag && !(fits_bits(dc, 4) && fits_bits(ds, 4))) atomicOr(plan.check_flag, 1u);
+            reinterpret_cast<uint8_t *>(table)[idx] = (uint8_t)(((uint32_t)dc & 0xFu) | (((uint32_t)ds & 0xFu) << 4));
+        } else {
+            if (plan.check_flag && !(fits_bits(dc, 8) && fits_bits(ds, 8))) atomicOr(plan.check_flag, 1u);
+            reinterpret_cast<uint16_t *>(table)[idx] = (uint16_t)(((uint32_t)dc & 0xFFu) | (((uint32_t)ds & 0xFFu) << 8));
+        }
+    };
+
+    // ---- phase 2: one wave per group, one lane per leaf (and its image) ----
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    // split layout: index of leaf (g, lane) = idx_a + g * idx_m; index of its image E - u = idx_i - (that)
+    uint32_t idx_a, idx_m, idx_i;
+    if (lane & 1u)      { idx_a = (E >> 1) + (lane >> 1); idx_m = 32u; idx_i = E + (E >> 1) - 1u; }
+    else if (lane & 2u) { idx_a = (E >> 2) + (lane >> 2); idx_m = 16u; idx_i = (E >> 1) + (E >> 2) - 1u; }
+    else                { idx_a = lane >> 2;              idx_m = 16u; idx_i = E >> 2; }
+    const uint32_t fmask = (1u << d) - 1u;
+    for (uint32_t gi = wave; gi < gpw; gi += kBuildThreads / 64) {
+        const uint32_t g = group0 + gi;
+        if (g >= n_groups) break;
+        int64_t x = gx[gi], y = gy[gi];
+        int32_t z = (int32_t)((uint32_t)gz[gi] + (lane << s));
+        const int32_t z_start = z;
+        const int k0 = __builtin_amdgcn_readfirstlane(gk[gi]);
+        uint64_t zmask = 0ull;                                       // lanes whose z_k was exactly 0 at a rotation before KS
+#pragma unroll
+        for (int k = 1; k < KS; ++k) {
+            if (k >= kcap || k >= k0) {
+                zmask |= __builtin_amdgcn_ballot_w64(z == 0);
+                rot_step(x, y, z, k, plan.lut[k]);
+            }
+        }
+        int64_t x2 = y, y2 = x;                                      // image chain at rotation KS
+        int32_t z2 = -z;
+        bool deferred = false;                                       // this lane's image goes to the worklist
+        if (zmask != 0ull) {                                         // scalar
+            const uint32_t u_ = (g << 6) + lane;
+            if (((zmask >> lane) & 1ull) != 0ull && u_ >= 1u && u_ <= m_last) {
+                const uint32_t slot = atomicAdd(&work_n, 1u);
+                if (slot < kWorkMax) { work_u[slot] = u_; deferred = true; }
+                else {                                               // list full (never seen): the image chain from scratch, in place
+                    int64_t xf = plan.x0, yf = plan.x0;
+                    int32_t zf = (int32_t)(((E - u_) << s) - lut_s[0]);
+#pragma unroll 1
+                    for (int r = 1; r < KS; ++r) rot_step(xf, yf, zf, r, lut_s[r]);
+                    x2 = xf; y2 = yf; z2 = zf;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = KS; k < NITER; ++k) {
+            rot_step(x, y, z, k, plan.lut[k]);
+            rot_step(x2, y2, z2, k, plan.lut[k]);
+        }
+        const uint32_t u = (g << 6) + lane;
+        const uint32_t idx = idx_a + g * idx_m;
+        store_entry(idx, (int32_t)(x >> plan.out_shr), (int32_t)(y >> plan.out_shr), record(0, (g << 6) >> d), ((g << 6) & fmask) + lane);
+        int32_t c2 = (int32_t)(x2 >> plan.out_shr), s2 = (int32_t)(y2 >> plan.out_shr);
+        if (lane == 0u && u >= 1u && u <= m_last && gflag[gi]) {      // rare: the shared prefix is not mirrored for leaf 0
+            int64_t xf = plan.x0, yf = plan.x0;
+            int32_t zf = (int32_t)(((E - u) << s) - lut_s[0]);
+#pragma unroll 1
+            for (int r = 1; r < n_iter; ++r) rot_step(xf, yf, zf, r, lut_s[r]);
+            c2 = (int32_t)(xf >> plan.out_shr);
+            s2 = (int32_t)(yf >> plan.out_shr);
+        }
+        if (u >= 1u && u <= m_last && !deferred) {
+            // images E - 64g - 63 .. E - 64g, descending with the lane: one cell, or two when lane 0's image opens the next one
+            const uint32_t um = E - u;
+            const uint32_t top = E - (g << 6), cell_a = (top - 63u) >> d, cell_b = top >> d;       // wave-uniform
+            const uint32_t cell_c = cell_a >= cell_lo[1] ? cell_a : cell_lo[1];                      // (sources above m_last are masked off)
+            int4 rec2 = record(1, cell_c);
+            if (__builtin_amdgcn_readfirstlane(cell_b) != __builtin_amdgcn_readfirstlane(cell_c)) { // scalar branch, 1 group in 2^(d-6)
+                const int4 rb = record(1, cell_b);
+                if (lane == 0u) rec2 = rb;
+            }
+            store_entry(idx_i - idx, c2, s2, rec2, um & fmask);
+        }
+    }
+    // ---- the deferred images: one lane each, the whole chain ----
+    __syncthreads();
+    const uint32_t n_work = work_n < kWorkMax ? work_n : kWorkMax;
+    for (uint32_t i = threadIdx.x; i < n_work; i += kBuildThreads) {
+        const uint32_t um = E - work_u[i];
+        int64_t xf = plan.x0, yf = plan.x0;
+        int32_t zf = (int32_t)((um << s) - lut_s[0]);
+#pragma unroll 1
+        for (int r = 1; r < n_iter; ++r) rot_step(xf, yf, zf, r, lut_s[r]);
+        store_entry(tab_index(um, plan.log2_entries, 1u), (int32_t)(xf >> plan.out_shr), (int32_t)(yf >> plan.out_shr), record_of(1, um >> d), um & fmask);
     }
 }
 
@@ -2460,6 +2701,26 @@ int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table
         // therefore at least 21 rotations: the VHDL model at PW == W runs W - 1 of them) from 21 rotations on
         const int fmt = fmt_of(c.tab_dlog);
         if (c.n_iter < 21 && fmt != 0) return (int)hipErrorInvalidValue;
+        // octant mirror (k_table_build_mirror): residual / nibble entries in the split layout, tables of 2^20 entries and more, and
+        // the exact quarter turn 2 * lut[0] == E << z_shl the symmetry rests on (true for every model at z_shr == 0; checked)
+#ifndef BHW_BUILD_MIRROR
+#define BHW_BUILD_MIRROR 1
+#endif
+        if (BHW_BUILD_MIRROR && (fmt == 2 || fmt == 3) && c.tab_split && c.z_shr == 0 && entries >= (1u << 20) && c.n_iter >= 21 &&
+            2ull * (uint64_t)plan.lut[0] == ((uint64_t)entries << c.z_shl)) {
+            const unsigned own_groups = (entries >> 7) + 1u;
+            const dim3 mgrid((own_groups + BHW_MIRROR_GPW - 1) / BHW_MIRROR_GPW);
+            plan.groups_per_wg = BHW_MIRROR_GPW;
+            switch (c.n_iter) {
+#define BHW_CASE_M(N) case N: if (fmt == 2) BHW_LAUNCH((k_table_build_mirror<N, 2>), mgrid, block, 0, st, plan, (void *)d_table); \
+                              else          BHW_LAUNCH((k_table_build_mirror<N, 3>), mgrid, block, 0, st, plan, (void *)d_table); break;
+                BHW_CASE_M(21) BHW_CASE_M(22) BHW_CASE_M(23) BHW_CASE_M(24) BHW_CASE_M(25) BHW_CASE_M(26) BHW_CASE_M(27) BHW_CASE_M(28)
+                BHW_CASE_M(29) BHW_CASE_M(30) BHW_CASE_M(31) BHW_CASE_M(32)
+#undef BHW_CASE_M
+            default: return (int)hipErrorInvalidValue;
+            }
+            return finish(hipSuccess);
+        }
 #define BHW_LAUNCH_BUILD(N, F) BHW_LAUNCH((k_table_build_shared<N, F>), grid, block, 0, st, plan, (void *)d_table)
 #define BHW_CASE(N) case N: BHW_LAUNCH_BUILD(N, 0); break;
 #define BHW_CASE_T(N) case N: if (fmt == 0) BHW_LAUNCH_BUILD(N, 0); else if (fmt == 1) BHW_LAUNCH_BUILD(N, 1); else if (fmt == 2) BHW_LAUNCH_BUILD(N, 2); else BHW_LAUNCH_BUILD(N, 3); break;
