@@ -1027,7 +1027,9 @@ int bhw_generate_part_device(const bhw_params *p, int device, void *hip_stream, 
     bool fused;
     if (req == BHW_ALGO_FUSED) fused = fused_ok;
     else if (req == BHW_ALGO_TABLE) fused = !table_ok;
-    else fused = fused_ok && (!table_ok || chains_fused * 4 <= table_entries(c) * 5);   // measured: even at 1.12 x the table's chains (G = 4)
+    else fused = fused_ok && (!table_ok || chains_fused <= table_entries(c));
+    // measured (BH-7 2^26 / 32-bit, profiles/r02_small_windows_and_parts.json): fused = 0.085 ms x chains_fused / entries, table =
+    // 0.073 ms + 0.063 ms / n_parts -> they cross at 1.04 x the table's chains (between 4 and 5 parts)
     if (fused) {
         if (!fused_ok) return fail(BHW_ERR_UNSUPPORTED, "no kernel produces this part (CORDIC state beyond 34 bits and no tile plan)");
         const int e = bhwk_fold_direct(l, c, w, runs, (uint32_t)n_runs, d_window);

@@ -2659,6 +2659,18 @@ uint32_t bhwk_resid_dlog(const BhwCordicCfg &c)
     return (uint32_t)d;
 }
 
+// octant mirror (k_table_build_mirror): residual / nibble entries in the split layout, tables of 2^20 entries and more, and the
+// exact quarter turn 2 * lut[0] == E << z_shl the symmetry rests on (true for every model at z_shr == 0; checked, not assumed)
+#ifndef BHW_BUILD_MIRROR
+#define BHW_BUILD_MIRROR 1
+#endif
+static bool build_mirror_applies(const BhwCordicCfg &c, uint32_t entries)
+{
+    const int fmt = fmt_of(c.tab_dlog);
+    return BHW_BUILD_MIRROR && (fmt == 2 || fmt == 3) && c.tab_split && c.z_shr == 0 && entries >= (1u << 20) && c.n_iter >= 21 &&
+           c.dat_width + c.out_shr <= 34 && 2ull * (uint64_t)(uint32_t)c.lut[0] == ((uint64_t)entries << c.z_shl);
+}
+
 int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table)
 {
     BHW_SET_DEVICE(l);
@@ -2701,13 +2713,7 @@ int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table
         // therefore at least 21 rotations: the VHDL model at PW == W runs W - 1 of them) from 21 rotations on
         const int fmt = fmt_of(c.tab_dlog);
         if (c.n_iter < 21 && fmt != 0) return (int)hipErrorInvalidValue;
-        // octant mirror (k_table_build_mirror): residual / nibble entries in the split layout, tables of 2^20 entries and more, and
-        // the exact quarter turn 2 * lut[0] == E << z_shl the symmetry rests on (true for every model at z_shr == 0; checked)
-#ifndef BHW_BUILD_MIRROR
-#define BHW_BUILD_MIRROR 1
-#endif
-        if (BHW_BUILD_MIRROR && (fmt == 2 || fmt == 3) && c.tab_split && c.z_shr == 0 && entries >= (1u << 20) && c.n_iter >= 21 &&
-            2ull * (uint64_t)plan.lut[0] == ((uint64_t)entries << c.z_shl)) {
+        if (build_mirror_applies(c, entries)) {
             const unsigned own_groups = (entries >> 7) + 1u;
             const dim3 mgrid((own_groups + BHW_MIRROR_GPW - 1) / BHW_MIRROR_GPW);
             plan.groups_per_wg = BHW_MIRROR_GPW;
@@ -2922,7 +2928,8 @@ void bhwk_describe_table(const BhwCordicCfg &c, const BhwWinCfg &w, bool tiled, 
     const bool fits = (c.dat_width + c.out_shr <= 34);
     const int fmt = fmt_of(c.tab_dlog);
     if (fits && c.n_iter >= 7 && entries < (1u << 20) && c.tab_dlog == 0 && !c.tab_split) snprintf(build, len, "k_table_build_plain<%u>", c.n_iter);
-    else if (entries >= 64 && fits && c.n_iter >= 2) snprintf(build, len, "k_table_build_shared<%u,%d>", c.n_iter, fmt);
+    else if (entries >= 64 && fits && c.n_iter >= 2)
+        snprintf(build, len, build_mirror_applies(c, entries) ? "k_table_build_mirror<%u,%d>" : "k_table_build_shared<%u,%d>", c.n_iter, fmt);
     else snprintf(build, len, "k_table_build<%s>", c.wide ? "int64_t" : "int32_t");
     const int mode = (w.combine != BHW_COMBINE_HLS) ? 2 : (c.ones_neg ? 1 : 0);
     if (tiled) {
