@@ -138,7 +138,7 @@ __device__ __forceinline__ T ld_off(const void *__restrict__ base, uint32_t byte
 // issues in ~4.1 cycles against ~2.5 with VGPR / inline-constant operands (profiles/r02_ubench_gfx950.txt), so the tile
 // kernel, which shifts and masks by these per gather, keeps them in VGPRs; everyone else passes the scalars.
 #ifndef BHW_TILE_DBG
-#define BHW_TILE_DBG 0      // timing experiments only (tools/ab_inproc.py with AB_NOCHECK): 1 no record loads, 2 no residual loads, 4 no stores
+#define BHW_TILE_DBG 0      // timing experiments only (tools/ab_inproc.py with AB_NOCHECK): 4 no stores
 #endif
 struct ResidK {
     uint32_t d;       // log2 of the cell size
@@ -164,48 +164,21 @@ __device__ __forceinline__ int2 tab_fetch(const BhwCordicCfg &cfg, const void *_
     return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
 }
 
-// Record of u's cell: from global memory, or (LDS) from the copy the wave staged in shared memory -- `lrec` + `bias` is the
-// byte address of the record of cell 0 as the staged window sees it (tile kernel).
-template <bool LDS>
-__device__ __forceinline__ int4 resid_record(const BhwCordicCfg &cfg, uint32_t u, const ResidK &rk, const char *lrec, uint32_t bias)
-{
-#if BHW_TILE_DBG & 1
-    return make_int4((int32_t)u, (int32_t)~u, 3, 5);
-#else
-    if constexpr (LDS) return *reinterpret_cast<const int4 *>(lrec + (((u >> rk.d) << 4) + bias));
-    else return ld_off<int4>(cfg.tab_coarse, (u >> rk.d) << 4);
-#endif
-}
-
-// residual / nibble format, the entry's residual word already loaded
+// Residual / nibble entry of the tile kernel from the UNMASKED angle theta = K * (r + g * E/2) (u = theta mod E), its residual
+// word e already loaded.  LDS: the record comes from the copy the wave staged in shared memory; `bias` is the byte address of
+// the record of "cell 0" as that window sees it and absorbs the whole turns of theta (no run of such a tile wraps), so the cell
+// index needs no mask: shift, shift-add, ds_read.  Otherwise the record is read from the table's record array.
 template <int FMT, bool LDS>
-__device__ __forceinline__ int2 tab_finish(const BhwCordicCfg &cfg, uint32_t u, const ResidK &rk, const char *lrec, uint32_t bias, uint32_t e)
+__device__ __forceinline__ int2 resid_value(const BhwCordicCfg &cfg, uint32_t theta, uint32_t emask, const ResidK &rk, const char *lrec, uint32_t bias,
+                                            uint32_t e)
 {
-    const int2 p = tab_predict(resid_record<LDS>(cfg, u, rk, lrec, bias), u & rk.fmask, rk.d);
+    static_assert(FMT == 2 || FMT == 3, "residual / nibble entries");
+    int4 rec;
+    if constexpr (LDS) rec = *reinterpret_cast<const int4 *>(lrec + (((theta >> rk.d) << 4) + bias));
+    else rec = ld_off<int4>(cfg.tab_coarse, ((theta & emask) >> rk.d) << 4);
+    const int2 p = tab_predict(rec, theta & rk.fmask, rk.d);
     if constexpr (FMT == 3) return make_int2(p.x + ((int32_t)(e << 28) >> 28), p.y + ((int32_t)(e << 24) >> 28));
     else return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
-}
-
-template <int FMT, bool LDS = false>
-__device__ __forceinline__ int2 tab_fetch_k(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t idx, const ResidK &rk,
-                                            const char *lrec = nullptr, uint32_t bias = 0u)
-{
-    if constexpr (FMT == 3) {
-        const uint32_t e = ld_off<uint8_t>(table, idx);
-        const int2 p = tab_predict(resid_record<LDS>(cfg, u, rk, lrec, bias), u & rk.fmask, rk.d);
-        return make_int2(p.x + ((int32_t)(e << 28) >> 28), p.y + ((int32_t)(e << 24) >> 28));
-    } else if constexpr (FMT != 2) return tab_fetch<FMT>(cfg, table, u, idx);
-    else {
-#if BHW_TILE_DBG & 2
-        const uint32_t e = (idx * 0x9E37u) >> 16;
-#elif BHW_TILE_DBG & 8
-        const uint32_t e = ld_off<uint16_t>(table, (idx << 1) & 0xFFFFu);
-#else
-        const uint32_t e = ld_off<uint16_t>(table, idx << 1);
-#endif
-        const int2 p = tab_predict(resid_record<LDS>(cfg, u, rk, lrec, bias), u & rk.fmask, rk.d);
-        return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
-    }
 }
 
 template <int KCLASS = 0, int FMT = -1, int SPLIT = -1>
@@ -217,42 +190,31 @@ __device__ __forceinline__ int2 tab_load(const BhwCordicCfg &cfg, const void *__
 // Split layout, entries of one residue class (the odd harmonics of a lane: u = K*r has r's class for every odd K, and so has
 // the half-period image u + E/2):
 //   index(u) = (u >> s) | base,   s = 1 (u odd) or 2 (u even),  base = E/2 (u odd), E/4 (u % 4 == 2), 0 (u % 4 == 0)
-// -- the regions are sized so that base never overlaps the shifted index.  The byte offset index << LB (LB = log2 of the entry
-// size) is one shift of u by |s - LB| and an OR; split_class() folds the class once per run into one word
-//   cls = (base << LB) | shift_amount          (the shift amount sits below bit LB, where byte offsets have zeros)
-// so that  byte offset = (shift(u, cls) | cls) & ~(2^LB - 1): the hardware takes the shift amount from the low five bits of cls.
-// Two instructions instead of nine per gather.
+// -- the regions are sized so that base never overlaps the shifted index.  split_class() folds the class once per run into one
+// word the gathers of the run's odd harmonics share:
+//   plain (8-byte) and delta16 (4-byte) entries:  cls = (base << LB) | (LB - s),  byte offset = ((u << cls) | cls) & ~(2^LB - 1)
+//     (LB = log2 of the entry size; the hardware takes the shift amount from the low five bits of cls);
+//   residual (2-byte) and nibble (1-byte) entries:  cls = (E if base != 0) | amount,  amount = s - 1 / s,
+//     byte offset = (((theta & (E-1)) | cls) >> cls) [& ~1 for 2-byte entries]
+//     -- base << s is E for both non-zero bases, the low bits the amount sets in u are shifted out (or, s = 1, set already), and the
+//     mask of theta rides in the same v_and_or_b32: two instructions per gather from the unmasked angle.
 template <int FMT>
 __device__ __forceinline__ uint32_t split_class(uint32_t r, uint32_t log2_entries)
 {
-    constexpr uint32_t LB = (FMT == 2 || FMT == 3) ? 1u : FMT == 1 ? 2u : 3u;   // FMT 3: the word of FMT 2, the offset halved at the load
     const uint32_t e = 1u << log2_entries;
     const uint32_t s = (r & 1u) ? 1u : 2u;
+    if constexpr (FMT == 2 || FMT == 3) return ((r & 3u) ? e : 0u) | (FMT == 3 ? s : s - 1u);
+    constexpr uint32_t LB = FMT == 1 ? 2u : 3u;
     const uint32_t base = (r & 1u) ? (e >> 1) : (((r >> 1) & 1u) ? (e >> 2) : 0u);
-    const uint32_t amount = (FMT == 2 || FMT == 3) ? s - 1u : LB - s;   // FMT 2 / 3: right by s - 1 (0 / 1); else left by LB - s (0 .. 2)
-    return (base << LB) | amount;
+    return (base << LB) | (LB - s);                                  // left by LB - s (0 .. 2)
 }
 
-template <int FMT, bool LDS = false>
-__device__ __forceinline__ int2 tab_load_class(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t cls, const ResidK &rk,
-                                               const char *lrec = nullptr, uint32_t bias = 0u)
+// plain / delta16 entry of class `cls`
+template <int FMT>
+__device__ __forceinline__ int2 tab_load_class(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t cls)
 {
-    if constexpr (FMT == 3) {                                    // 1 byte per entry: index = the 2-byte offset halved
-        const uint32_t e = ld_off<uint8_t>(table, ((u >> (cls & 31u)) | cls) >> 1);
-        const int2 p = tab_predict(resid_record<LDS>(cfg, u, rk, lrec, bias), u & rk.fmask, rk.d);
-        return make_int2(p.x + ((int32_t)(e << 28) >> 28), p.y + ((int32_t)(e << 24) >> 28));
-    } else if constexpr (FMT == 2) {                             // 2 bytes per entry
-        const uint32_t boff = ((u >> (cls & 31u)) | cls) & ~1u;
-#if BHW_TILE_DBG & 2
-        const uint32_t e = (boff * 0x9E37u) >> 16;
-#elif BHW_TILE_DBG & 8
-        const uint32_t e = ld_off<uint16_t>(table, boff & 0xFFFFu);      // same instructions, a 64 KiB window: no fabric reads
-#else
-        const uint32_t e = ld_off<uint16_t>(table, boff);
-#endif
-        const int2 p = tab_predict(resid_record<LDS>(cfg, u, rk, lrec, bias), u & rk.fmask, rk.d);
-        return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
-    } else if constexpr (FMT == 1) {                             // 4 bytes per entry
+    static_assert(FMT == 0 || FMT == 1, "residual / nibble entries: resid_offset + resid_value");
+    if constexpr (FMT == 1) {                                    // 4 bytes per entry
         const uint32_t boff = ((u << (cls & 31u)) | cls) & ~3u;
         const uint32_t e = ld_off<uint32_t>(table, boff);
         const int2 base = ld_off<int2>(cfg.tab_coarse, (u >> kPackLog) << 3);
@@ -260,6 +222,27 @@ __device__ __forceinline__ int2 tab_load_class(const BhwCordicCfg &cfg, const vo
     } else {                                                     // 8 bytes per entry
         const uint32_t boff = ((u << (cls & 31u)) | cls) & ~7u;
         return ld_off<int2>(table, boff);
+    }
+}
+
+// Byte offset of the residual word of entry u = K * rg mod E (rg = r + g * E/2) in the split layout, residual / nibble formats.
+// Odd K: the class word (split_class).  Even K: u = 2w or 4w with w = (K/2) rg or (K/4) rg, and the index is a bit field of w --
+// (u >> 2) + (E/4 if u % 4 == 2) = w[lq-2:1] | w[0] << (lq-2), or u >> 2 = w mod E/4 -- three instructions / one.
+template <int FMT, int K>
+__device__ __forceinline__ uint32_t resid_offset(uint32_t rg, uint32_t theta, uint32_t cls, uint32_t lq, uint32_t emask)
+{
+    static_assert(FMT == 2 || FMT == 3, "residual / nibble entries");
+    if constexpr ((K & 1) != 0) {
+        const uint32_t t = ((theta & emask) | cls) >> (cls & 31u);
+        return FMT == 3 ? t : (t & ~1u);
+    } else if constexpr (K % 4 == 2) {
+        const uint32_t w = (uint32_t)(K / 2) * rg;
+        if constexpr (FMT == 3) return __builtin_amdgcn_ubfe(w, 1u, lq - 2u) | ((w & 1u) << (lq - 2u));
+        else return (w & ((1u << (lq - 1u)) - 2u)) | ((w & 1u) << (lq - 1u));
+    } else {
+        const uint32_t w = (uint32_t)(K / 4) * rg;
+        if constexpr (FMT == 3) return w & ((1u << (lq - 2u)) - 1u);
+        else return (w << 1) & ((1u << (lq - 1u)) - 2u);
     }
 }
 
@@ -625,7 +608,8 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
 // so the chain of u' = E - u is the chain of u with x and y swapped, z negated and every decision flipped -- bit for bit, floors
 // included -- as long as no z_k on the way is exactly 0 (z >= 0 rotates forward in both).  Zero events are common only in the last
 // rotations (|z| is a few units there), so:
-//   * only u in [0, E/2 + 64) run a chain of their own; u' in [E/2 + 64, E) are images of u in [1, E/2 - 64];
+//   * only u in [0, E/2) run a chain of their own; u' in (E/2, E) are images of u in [1, E/2 - 1]; the middle entry E/2 is a
+//     deferred chain of the last workgroup;
 //   * at rotation KS = NITER - BHW_MIRROR_TAIL the image state is taken as (y, x, -z) and the last rotations run for both;
 //   * a lane that met z_k == 0 before KS (one v_cmp per shared rotation, collected in a scalar mask; about 1 % of the lanes, but
 //     every second wave has one) does not store its image: it appends u to a worklist in shared memory, and after the groups
@@ -640,6 +624,12 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
 #ifndef BHW_MIRROR_GPW
 #define BHW_MIRROR_GPW 64
 #endif
+#ifndef BHW_MIRROR_EXACT
+#define BHW_MIRROR_EXACT 1          // own chains for u in [0, E/2) only (a power-of-two grid, no straggler workgroup); entry E/2 goes through the worklist.  0: one more group [E/2, E/2 + 64)
+#endif
+#ifndef BHW_MIRROR_WORKMAX
+#define BHW_MIRROR_WORKMAX 512      // worklist slots per workgroup (about 40 used); a build with 4 exercises the overflow path
+#endif
 template <int NITER, int FMT>
 __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPlan plan, void *__restrict__ table)
 {
@@ -650,23 +640,29 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
     __shared__ int32_t gk[kGroupsPerWg];
     __shared__ uint32_t gflag[kGroupsPerWg];
     __shared__ uint32_t lut_s[32];
-    constexpr uint32_t kWorkMax = 512;                               // images to run as chains of their own (expected ~40 per workgroup)
+    constexpr uint32_t kWorkMax = BHW_MIRROR_WORKMAX;                // images to run as chains of their own (expected ~40 per workgroup)
     __shared__ uint32_t work_n;
     __shared__ uint32_t work_u[kWorkMax];
     if (threadIdx.x < 32) lut_s[threadIdx.x] = plan.lut[threadIdx.x];
-    if (threadIdx.x == 0) work_n = 0u;
-    __syncthreads();
-
     constexpr int n_iter = NITER;
     constexpr int KS = NITER - BHW_MIRROR_TAIL;                      // image state taken at this rotation
     const uint32_t s = plan.z_shl;
     constexpr uint32_t gpw = BHW_MIRROR_GPW;                         // own groups per workgroup
     const uint32_t group0 = blockIdx.x * gpw;
     const uint32_t E = plan.entries;
-    const uint32_t n_groups = (E >> 7) + 1u;                         // groups that run chains of their own
+    const uint32_t n_groups = (E >> 7) + (BHW_MIRROR_EXACT ? 0u : 1u);   // groups that run chains of their own
     const uint32_t u_lo = group0 << 6;
     const uint32_t u_hi = ((group0 + gpw) << 6) < (n_groups << 6) ? ((group0 + gpw) << 6) : (n_groups << 6);   // own entries [u_lo, u_hi)
-    const uint32_t m_last = (E >> 1) - 64u;                          // u in [1, m_last] also produce the image E - u
+    const uint32_t m_last = (E >> 1) - (BHW_MIRROR_EXACT ? 1u : 64u);    // u in [1, m_last] also produce the image E - u
+    if (threadIdx.x == 0) {
+        work_n = 0u;
+        if (BHW_MIRROR_EXACT && u_hi == (E >> 1)) {                  // the middle entry E/2 (its own image): one more deferred chain
+            work_u[0] = E >> 1;
+            work_n = 1u;
+        }
+    }
+    __syncthreads();
+
 
     // records {c, s, dc, ds} of the cells this workgroup stores into: w = 0 its own range, w = 1 the image range.  Heads
     // lo .. lo + n, plus head lo - 1 for the table's last cell (see k_table_build_shared), by full chains of the second / third wave.
@@ -677,6 +673,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
     {
         const uint32_t a = u_lo > 1u ? u_lo : 1u, b = (u_hi - 1u) < m_last ? (u_hi - 1u) : m_last;        // sources a .. b
         if (a <= b) { r_lo[1] = E - b; r_hi[1] = E - a + 1u; }
+        if (BHW_MIRROR_EXACT && a <= b && b == (E >> 1) - 1u) r_lo[1] = E >> 1;      // the middle entry belongs to this image range
     }
 #pragma unroll
     for (int w = 0; w < 2; ++w)
@@ -1087,11 +1084,18 @@ __device__ __forceinline__ void tile_harmonic(const BhwCordicCfg &cfg, const int
     if constexpr (FAST && MODE != 2) {
         // four one-instruction products with the quadrant's own operand (-v or ~v); the harmonic's sign (-1)^K is NOT applied
         // here: all four candidates carry it alike, so tile_accumulate<K, OFF, true> subtracts instead of adding for odd K
-        const int32_t nc = MODE == 1 ? ~cs.x : -cs.x, ns = MODE == 1 ? ~cs.y : -cs.y;
         p0 = __mulhi(a, cs.x);
-        p1 = __mulhi(a, ns);
-        p2 = __mulhi(a, nc);
         p3 = __mulhi(a, cs.y);
+        if constexpr (MODE == 1) {
+            p1 = __mulhi(a, ~cs.y);
+            p2 = __mulhi(a, ~cs.x);
+        } else {
+            // a * (-v) is the same 64-bit product as (-a) * v: the negation moves to the weight (a scalar), two vector
+            // instructions fewer per gather (the callers keep a > -2^31; a table value is never -2^31)
+            const int32_t na = -a;
+            p1 = __mulhi(na, cs.y);
+            p2 = __mulhi(na, cs.x);
+        }
     } else if constexpr (MODE == 2) {
         const int32_t nc = cfg.ones_neg ? ~cs.x : -cs.x;
         const int32_t ns = cfg.ones_neg ? ~cs.y : -cs.y;
@@ -1427,13 +1431,14 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
 #define BHW_TILE_ISSUE(K)                                                                                \
         if (win.n_terms > K) {                                                                           \
             constexpr int NG = (K & 1) ? 2 : 1;                                                          \
-            constexpr int KC = (K % 4 == 0) ? 4 : (K % 2 == 0) ? 2 : 0;                                  \
             _Pragma("unroll") for (int b = B0; b < B1; ++b) {                                            \
                 _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                         \
                     if (MASKED && NG == 2 && !(g ? want1 : want0)) continue;                             \
-                    const uint32_t u = ((uint32_t)K * (rr[b] + (uint32_t)g * H)) & emask;                \
-                    const uint32_t idx2 = (K & 1) ? ((u >> (cls[b] & 31u)) | cls[b]) & ~1u : tab_index<KC, 1>(u, lq, 1u) << 1; \
-                    land[gather_order(K, b, g)] = FMT == 3 ? (uint32_t)ld_off<uint8_t>(table, idx2 >> 1) : (uint32_t)ld_off<uint16_t>(table, idx2); \
+                    if constexpr (FMT == 2 || FMT == 3) {                                               \
+                        const uint32_t rg = rr[b] + (uint32_t)g * H;                                     \
+                        const uint32_t boff = resid_offset<FMT, K>(rg, (uint32_t)K * rg, cls[b], lq, emask); \
+                        land[gather_order(K, b, g)] = FMT == 3 ? (uint32_t)ld_off<uint8_t>(table, boff) : (uint32_t)ld_off<uint16_t>(table, boff); \
+                    }                                                                                    \
                 }                                                                                        \
             }                                                                                            \
         }
@@ -1455,7 +1460,7 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
                 const uint32_t u0 = th0 & emask;
                 qpack[b] |= ((th0 >> lq) & 3u) << (2 * si);
                 wraps |= u0 + K * (uint32_t)(kLanes - 1) > emask;
-                rbias[si][b] = (((wave * NR + b) * kRecPerRun + (uint32_t)rec_set_base(si)) << 4) - ((u0 >> d) << 4);
+                rbias[si][b] = (((wave * NR + b) * kRecPerRun + (uint32_t)rec_set_base(si)) << 4) - ((th0 >> d) << 4);   // cell of the unmasked angle (resid_value)
             }
         }
         if constexpr (kPrefetch) {
@@ -1520,14 +1525,22 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
         _Pragma("unroll") for (int b = B0; b < B1; ++b) {                                                 \
             _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                             \
                 if (MASKED && NG == 2 && !(g ? want1 : want0)) continue;                                 \
-                const uint32_t theta = (uint32_t)K * (rr[b] + (uint32_t)g * H);                          \
-                const uint32_t bias = rbias[rec_set_index(K, g)][b];                                     \
-                if constexpr (kPrefetch && LDS) {                                                        \
-                    cs[b][g] = tab_finish<FMT, true>(cfg, theta & emask_v, rk, lrec, bias, land[gather_order(K, b, g)]); \
-                } else if constexpr (NB > 1 && (K & 1)) cs[b][g] = tab_load_class<FMT, LDS>(cfg, table, theta & emask_v, cls[b], rk, lrec, bias); \
+                const uint32_t rg = rr[b] + (uint32_t)g * H;                                             \
+                const uint32_t theta = (uint32_t)K * rg;                                                 \
+                if constexpr (NB > 1 && (FMT == 2 || FMT == 3)) {                                        \
+                    uint32_t bias = rbias[rec_set_index(K, g)][b];                                       \
+                    if constexpr (LDS) asm("" : "+s"(bias));    /* one scalar: the record address is shift, shift-add */ \
+                    uint32_t e;                                                                          \
+                    if constexpr (kPrefetch && LDS) e = land[gather_order(K, b, g)];                     \
+                    else {                                                                               \
+                        const uint32_t boff = resid_offset<FMT, K>(rg, theta, cls[b], lq, emask_v);     \
+                        e = FMT == 3 ? (uint32_t)ld_off<uint8_t>(table, boff) : (uint32_t)ld_off<uint16_t>(table, boff); \
+                    }                                                                                    \
+                    cs[b][g] = resid_value<FMT, LDS>(cfg, theta, emask_v, rk, lrec, bias, e);            \
+                } else if constexpr (NB > 1 && (K & 1)) cs[b][g] = tab_load_class<FMT>(cfg, table, theta & emask_v, cls[b]); \
                 else if constexpr (NB > 1) {                                                             \
                     const uint32_t u = theta & emask_v;                                                  \
-                    cs[b][g] = tab_fetch_k<FMT, LDS>(cfg, table, u, tab_index<KC, 1>(u, lq, 1u), rk, lrec, bias); \
+                    cs[b][g] = tab_fetch<FMT>(cfg, table, u, tab_index<KC, 1>(u, lq, 1u));              \
                 } else cs[b][g] = tab_load<KC, FMT, -1>(cfg, table, (theta & emask) >> cfg.z_shr, lq - cfg.z_shr); \
             }                                                                                            \
         }                                                                                                \
@@ -2714,7 +2727,7 @@ int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table
         const int fmt = fmt_of(c.tab_dlog);
         if (c.n_iter < 21 && fmt != 0) return (int)hipErrorInvalidValue;
         if (build_mirror_applies(c, entries)) {
-            const unsigned own_groups = (entries >> 7) + 1u;
+            const unsigned own_groups = (entries >> 7) + (BHW_MIRROR_EXACT ? 0u : 1u);
             const dim3 mgrid((own_groups + BHW_MIRROR_GPW - 1) / BHW_MIRROR_GPW);
             plan.groups_per_wg = BHW_MIRROR_GPW;
             switch (c.n_iter) {
@@ -2865,7 +2878,7 @@ int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c, con
     bool fast = BHW_TILE_FASTMUL && mode != 2 && nb == 15 && c.dat_width >= 3;
     for (uint32_t k = 1; k < w.n_terms && fast; ++k) {
         const int64_t lim = (int64_t)1 << (c.dat_width - 3);
-        fast = (int64_t)w.aa[k] < lim && (int64_t)w.aa[k] >= -lim;
+        fast = (int64_t)w.aa[k] < lim && (int64_t)w.aa[k] > -lim;       // (> : the kernel also multiplies by the negated pre-shifted weight)
     }
 #define BHW_LAUNCH_TILE_MFK(NB, M, F, K)                                                                                 \
     do {                                                                                                                 \
@@ -3004,7 +3017,7 @@ int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg 
     plan.fast_mul = (w.combine == BHW_COMBINE_HLS && c.dat_width >= 3) ? 1u : 0u;
     for (uint32_t k = 1; k < w.n_terms && plan.fast_mul; ++k) {
         const int64_t lim = (int64_t)1 << (c.dat_width - 3);
-        if ((int64_t)w.aa[k] >= lim || (int64_t)w.aa[k] < -lim) plan.fast_mul = 0u;
+        if ((int64_t)w.aa[k] >= lim || (int64_t)w.aa[k] <= -lim) plan.fast_mul = 0u;
     }
     uint64_t total = 0;
     for (uint32_t i = 0; i < n_runs; ++i) total += runs[i].r_end - runs[i].r0;
