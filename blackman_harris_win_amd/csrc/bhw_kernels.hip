@@ -194,16 +194,15 @@ __device__ __forceinline__ int2 tab_load(const BhwCordicCfg &cfg, const void *__
 // word the gathers of the run's odd harmonics share:
 //   plain (8-byte) and delta16 (4-byte) entries:  cls = (base << LB) | (LB - s),  byte offset = ((u << cls) | cls) & ~(2^LB - 1)
 //     (LB = log2 of the entry size; the hardware takes the shift amount from the low five bits of cls);
-//   residual (2-byte) and nibble (1-byte) entries:  cls = (E if base != 0) | amount,  amount = s - 1 / s,
-//     byte offset = (((theta & (E-1)) | cls) >> cls) [& ~1 for 2-byte entries]
-//     -- base << s is E for both non-zero bases, the low bits the amount sets in u are shifted out (or, s = 1, set already), and the
-//     mask of theta rides in the same v_and_or_b32: two instructions per gather from the unmasked angle.
+//   residual (2-byte) entries:  cls = (E if base != 0) | (s - 1),  byte offset = (((theta & (E-1)) | cls) >> cls) & ~1
+//     -- base << s is E for both non-zero bases, the low bit the amount sets in u is shifted out, and the mask of theta rides in
+//     the same v_and_or_b32: three instructions per gather from the unmasked angle (nibble tables are not split: resid_offset).
 template <int FMT>
 __device__ __forceinline__ uint32_t split_class(uint32_t r, uint32_t log2_entries)
 {
     const uint32_t e = 1u << log2_entries;
     const uint32_t s = (r & 1u) ? 1u : 2u;
-    if constexpr (FMT == 2 || FMT == 3) return ((r & 3u) ? e : 0u) | (FMT == 3 ? s : s - 1u);
+    if constexpr (FMT == 2 || FMT == 3) return ((r & 3u) ? e : 0u) | (s - 1u);      // (FMT 3: unused, natural layout)
     constexpr uint32_t LB = FMT == 1 ? 2u : 3u;
     const uint32_t base = (r & 1u) ? (e >> 1) : (((r >> 1) & 1u) ? (e >> 2) : 0u);
     return (base << LB) | (LB - s);                                  // left by LB - s (0 .. 2)
@@ -225,24 +224,26 @@ __device__ __forceinline__ int2 tab_load_class(const BhwCordicCfg &cfg, const vo
     }
 }
 
-// Byte offset of the residual word of entry u = K * rg mod E (rg = r + g * E/2) in the split layout, residual / nibble formats.
-// Odd K: the class word (split_class).  Even K: u = 2w or 4w with w = (K/2) rg or (K/4) rg, and the index is a bit field of w --
-// (u >> 2) + (E/4 if u % 4 == 2) = w[lq-2:1] | w[0] << (lq-2), or u >> 2 = w mod E/4 -- three instructions / one.
+// Byte offset of the residual word of entry u = K * rg mod E (rg = r + g * E/2), tile kernel.
+// Nibble format (one byte per entry, natural layout): u itself.  With one-byte entries a wave's gather of harmonic K spans
+// K * 64 bytes either way, the K = 1 gathers become unit-stride loads (4.7 instead of 16.4 cycles of the CU's address path,
+// profiles/r02_ubench_vmem.txt) and the address is one instruction: -1.0 % on the whole call against the split layout.
+// Residual format (two bytes per entry, split layout: natural is 2.9 % slower there).  Odd K: the class word (split_class).
+// Even K: u = 2w or 4w with w = (K/2) rg or (K/4) rg, and the index is a bit field of w --
+// (u >> 2) + (E/4 if u % 4 == 2) = w[lq-2:1] | w[0] << (lq-2), or u >> 2 = w mod E/4 -- three instructions / two.
 template <int FMT, int K>
 __device__ __forceinline__ uint32_t resid_offset(uint32_t rg, uint32_t theta, uint32_t cls, uint32_t lq, uint32_t emask)
 {
     static_assert(FMT == 2 || FMT == 3, "residual / nibble entries");
-    if constexpr ((K & 1) != 0) {
-        const uint32_t t = ((theta & emask) | cls) >> (cls & 31u);
-        return FMT == 3 ? t : (t & ~1u);
+    if constexpr (FMT == 3) return theta & emask;                  // nibble tables keep the natural layout (table_layout)
+    else if constexpr ((K & 1) != 0) {
+        return (((theta & emask) | cls) >> (cls & 31u)) & ~1u;
     } else if constexpr (K % 4 == 2) {
         const uint32_t w = (uint32_t)(K / 2) * rg;
-        if constexpr (FMT == 3) return __builtin_amdgcn_ubfe(w, 1u, lq - 2u) | ((w & 1u) << (lq - 2u));
-        else return (w & ((1u << (lq - 1u)) - 2u)) | ((w & 1u) << (lq - 1u));
+        return (w & ((1u << (lq - 1u)) - 2u)) | ((w & 1u) << (lq - 1u));
     } else {
         const uint32_t w = (uint32_t)(K / 4) * rg;
-        if constexpr (FMT == 3) return w & ((1u << (lq - 2u)) - 1u);
-        else return (w << 1) & ((1u << (lq - 1u)) - 2u);
+        return (w << 1) & ((1u << (lq - 1u)) - 2u);
     }
 }
 
@@ -767,11 +768,12 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
 
     // ---- phase 2: one wave per group, one lane per leaf (and its image) ----
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    // split layout: index of leaf (g, lane) = idx_a + g * idx_m; index of its image E - u = idx_i - (that)
+    // index of leaf (g, lane) = idx_a + g * idx_m; index of its image E - u = idx_i - (that) -- split layout per residue class of the lane
     uint32_t idx_a, idx_m, idx_i;
     if (lane & 1u)      { idx_a = (E >> 1) + (lane >> 1); idx_m = 32u; idx_i = E + (E >> 1) - 1u; }
     else if (lane & 2u) { idx_a = (E >> 2) + (lane >> 2); idx_m = 16u; idx_i = (E >> 1) + (E >> 2) - 1u; }
     else                { idx_a = lane >> 2;              idx_m = 16u; idx_i = E >> 2; }
+    if (!plan.tab_split) { idx_a = lane; idx_m = 64u; idx_i = E; }  // natural layout (nibble tables): index u, image E - u
     const uint32_t fmask = (1u << d) - 1u;
     for (uint32_t gi = wave; gi < gpw; gi += kBuildThreads / 64) {
         const uint32_t g = group0 + gi;
@@ -844,7 +846,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
         int32_t zf = (int32_t)((um << s) - lut_s[0]);
 #pragma unroll 1
         for (int r = 1; r < n_iter; ++r) rot_step(xf, yf, zf, r, lut_s[r]);
-        store_entry(tab_index(um, plan.log2_entries, 1u), (int32_t)(xf >> plan.out_shr), (int32_t)(yf >> plan.out_shr), record_of(1, um >> d), um & fmask);
+        store_entry(tab_index(um, plan.log2_entries, plan.tab_split), (int32_t)(xf >> plan.out_shr), (int32_t)(yf >> plan.out_shr), record_of(1, um >> d), um & fmask);
     }
 }
 
@@ -1491,7 +1493,11 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
 #ifndef BHW_TILE_VGPR_CONSTS
 #define BHW_TILE_VGPR_CONSTS 0      // measured: 1 is 1 % slower (profiles/r02_ab_tile_kernel_steps.txt) -- register pressure outweighs the cheaper operands
 #endif
+#ifdef BHW_TILE_FIXD      // timing experiment: the cell size as a compile-time constant (immediate shifts and mask)
+    ResidK rk{BHW_TILE_FIXD, (1u << BHW_TILE_FIXD) - 1u};
+#else
     ResidK rk{fmt_cell_log(cfg.tab_dlog), (1u << fmt_cell_log(cfg.tab_dlog)) - 1u};
+#endif
     uint32_t emask_v = emask, lq_v = lq;                            // per-gather shift / mask operands: VGPR copies (see ResidK)
 #if BHW_TILE_VGPR_CONSTS
     asm volatile("" : "+v"(rk.d), "+v"(rk.fmask), "+v"(emask_v), "+v"(lq_v));
@@ -2672,7 +2678,15 @@ uint32_t bhwk_resid_dlog(const BhwCordicCfg &c)
     return (uint32_t)d;
 }
 
-// octant mirror (k_table_build_mirror): residual / nibble entries in the split layout, tables of 2^20 entries and more, and the
+// The layout goes with the format: nibble tables are always in the natural order (resid_offset), whatever the caller asked for.
+static BhwCordicCfg table_layout(const BhwCordicCfg &c)
+{
+    BhwCordicCfg n = c;
+    if (fmt_of(c.tab_dlog) == 3) n.tab_split = 0u;
+    return n;
+}
+
+// octant mirror (k_table_build_mirror): residual / nibble entries, tables of 2^20 entries and more, and the
 // exact quarter turn 2 * lut[0] == E << z_shl the symmetry rests on (true for every model at z_shr == 0; checked, not assumed)
 #ifndef BHW_BUILD_MIRROR
 #define BHW_BUILD_MIRROR 1
@@ -2680,12 +2694,13 @@ uint32_t bhwk_resid_dlog(const BhwCordicCfg &c)
 static bool build_mirror_applies(const BhwCordicCfg &c, uint32_t entries)
 {
     const int fmt = fmt_of(c.tab_dlog);
-    return BHW_BUILD_MIRROR && (fmt == 2 || fmt == 3) && c.tab_split && c.z_shr == 0 && entries >= (1u << 20) && c.n_iter >= 21 &&
+    return BHW_BUILD_MIRROR && (fmt == 2 || fmt == 3) && (c.tab_split || fmt == 3) && c.z_shr == 0 && entries >= (1u << 20) && c.n_iter >= 21 &&
            c.dat_width + c.out_shr <= 34 && 2ull * (uint64_t)(uint32_t)c.lut[0] == ((uint64_t)entries << c.z_shl);
 }
 
-int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table)
+int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c_in, int32_t *d_table)
 {
+    const BhwCordicCfg c = table_layout(c_in);
     BHW_SET_DEVICE(l);
     hipStream_t st = (hipStream_t)l.stream;
     const uint32_t entries = 1u << (c.phi_width - 2 - c.z_shr);
@@ -2761,9 +2776,10 @@ int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table
     return finish(hipSuccess);
 }
 
-int bhwk_table_combine(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table,
+int bhwk_table_combine(const BhwLaunch &l, const BhwCordicCfg &c_in, const BhwWinCfg &w, const int32_t *d_table,
                        uint64_t n0, uint64_t count, int32_t *d_out)
 {
+    const BhwCordicCfg c = table_layout(c_in);
     if (!count) return 0;
     BHW_SET_DEVICE(l);
     hipStream_t st = (hipStream_t)l.stream;
@@ -2771,8 +2787,9 @@ int bhwk_table_combine(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCf
     return finish(hipSuccess);
 }
 
-int bhwk_table_combine_fold(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out)
+int bhwk_table_combine_fold(const BhwLaunch &l, const BhwCordicCfg &c_in, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out)
 {
+    const BhwCordicCfg c = table_layout(c_in);
     BHW_SET_DEVICE(l);
     hipStream_t st = (hipStream_t)l.stream;
     const uint32_t quarter = 1u << (c.phi_width - 2);
@@ -2852,9 +2869,10 @@ static void make_tile_plan(const BhwCordicCfg &c, const BhwWinCfg &w, BhwTilePla
 }
 
 // Tiles [tile0, tile0 + tile_count) of the plan (tile_count 0: all of them).
-int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out,
+int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c_in, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out,
                                   uint32_t tile0, uint32_t tile_count, uint32_t img_mask, uint32_t n0mod)
 {
+    const BhwCordicCfg c = table_layout(c_in);
     BHW_SET_DEVICE(l);
     hipStream_t st = (hipStream_t)l.stream;
     BhwTilePlan tp;
@@ -2935,8 +2953,9 @@ bool bhwk_tile_images_applicable(const BhwCordicCfg &c, const BhwWinCfg &w, uint
 
 // Kernel names of the table strategy's two passes for a resolved configuration (bhw_describe_plan: profilers, bench labels).
 // Mirrors the dispatch in bhwk_table_build / bhwk_table_combine_tile_range / bhwk_table_combine_fold.
-void bhwk_describe_table(const BhwCordicCfg &c, const BhwWinCfg &w, bool tiled, char *build, char *combine, size_t len)
+void bhwk_describe_table(const BhwCordicCfg &c_in, const BhwWinCfg &w, bool tiled, char *build, char *combine, size_t len)
 {
+    const BhwCordicCfg c = table_layout(c_in);
     const uint32_t entries = 1u << (c.phi_width - 2 - c.z_shr);
     const bool fits = (c.dat_width + c.out_shr <= 34);
     const int fmt = fmt_of(c.tab_dlog);

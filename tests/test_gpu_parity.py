@@ -298,6 +298,22 @@ def test_tile_path_with_wrapping_caller_weights(torch, win, w, combine):
     assert np.array_equal(gpu_generate(p, 0, n, B.ALGO_TABLE), O.generate_mt(O.from_bhw(p), 0, n))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("w", [32, 28])
+def test_weights_at_the_edge_of_the_one_instruction_products(torch, w):
+    """The tile and fused kernels multiply by the pre-shifted weight a << (34 - W) and by its negation when every |a_k| is below
+    2^(W-3): weights at +-(2^(W-3) - 1) take that form, a weight of exactly -2^(W-3) (whose negation does not fit) must not."""
+    import blackman_harris_win_amd as bhw
+    lim = 1 << (w - 3)
+    n = 1 << 22
+    for aa in ([lim - 1, -(lim - 1), lim - 1, -(lim - 1), lim - 1, -(lim - 1), lim - 1],
+               [lim - 1, -lim, lim - 1, 12345, -lim, 777, -lim]):
+        p = B.make_params(7, 22, w, aa=aa)
+        want = O.generate_mt(O.from_bhw(p), 0, n)
+        assert np.array_equal(gpu_generate(p, 0, n, B.ALGO_TABLE), want), aa
+        assert np.array_equal(bhw.generate(p, 0, n, algo=B.ALGO_FUSED).cpu().numpy(), want), aa
+
+
 def test_strategies_agree_on_random_whole_windows(torch):
     """Size-independent property: DIRECT (one CORDIC chain per harmonic per coefficient) and TABLE (shared table,
     folds, gather tiles) are different computations of the same integers -- whole windows must be identical."""
