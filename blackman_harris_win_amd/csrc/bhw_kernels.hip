@@ -176,6 +176,8 @@ __device__ __forceinline__ int2 resid_value(const BhwCordicCfg &cfg, uint32_t th
     int4 rec;
     if constexpr (LDS) rec = *reinterpret_cast<const int4 *>(lrec + (((theta >> rk.d) << 4) + bias));
     else rec = ld_off<int4>(cfg.tab_coarse, ((theta & emask) >> rk.d) << 4);
+    // (the predictor as two shifts + two v_mul_hi_i32 on doubled slopes -- one instruction fewer per gather -- measured slower:
+    // 0.1358 -> 0.1367 ms, profiles/r02_ab_tile_memory_path.txt)
     const int2 p = tab_predict(rec, theta & rk.fmask, rk.d);
     if constexpr (FMT == 3) return make_int2(p.x + ((int32_t)(e << 28) >> 28), p.y + ((int32_t)(e << 24) >> 28));
     else return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
@@ -235,7 +237,10 @@ template <int FMT, int K>
 __device__ __forceinline__ uint32_t resid_offset(uint32_t rg, uint32_t theta, uint32_t cls, uint32_t lq, uint32_t emask)
 {
     static_assert(FMT == 2 || FMT == 3, "residual / nibble entries");
-    if constexpr (FMT == 3) return theta & emask;                  // nibble tables keep the natural layout (table_layout)
+    if constexpr (FMT == 3) {                                       // nibble tables keep the natural layout (table_layout)
+        if constexpr (K <= 2) return theta;                        // K (r + g E/2) < E for r < E/2: nothing to wrap
+        else return theta & emask;
+    }
     else if constexpr ((K & 1) != 0) {
         return (((theta & emask) | cls) >> (cls & 31u)) & ~1u;
     } else if constexpr (K % 4 == 2) {
@@ -540,7 +545,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
     }
 
     // ---- phase 2: one wave per group, one lane per leaf, remaining rotations only ----
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;   // g and what derives from it stay scalar
     // table index of leaf (g, lane) = idx_a + g * idx_m: natural layout 64 g + lane; split layout per residue class of the lane
     // (64 g + lane has the lane's residue mod 4), tab_index() folded into two per-lane constants
     uint32_t idx_a = lane, idx_m = 64u;
@@ -551,7 +556,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
         else                { idx_a = lane >> 2;              idx_m = 16u; }
     }
     for (uint32_t gi = wave; gi < gpw; gi += kBuildThreads / 64) {
-        const uint32_t g = group0 + gi;
+        const uint32_t g = __builtin_amdgcn_readfirstlane(group0 + gi);
         if (g >= n_groups) break;
         int64_t x = gx[gi], y = gy[gi];
         int32_t z = (int32_t)((uint32_t)gz[gi] + (lane << s));
@@ -735,23 +740,28 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
     }
     __syncthreads();
 
-    auto record_of = [&](int w, uint32_t cell) -> int4 {           // cell in [cell_lo[w], cell_lo[w] + n_cell[w])
-        const uint32_t t = cell - cell_lo[w];
-        if (cell + 1u < cells_total) return make_int4(hc[w][t], hs[w][t], hc[w][t + 1] - hc[w][t], hs[w][t + 1] - hs[w][t]);
-        const uint32_t tp = t ? t - 1u : n_cell[w] + 1u;             // last cell of the table: slope of the cell before it
-        return make_int4(hc[w][t], hs[w][t], hc[w][t] - hc[w][tp], hs[w][t] - hs[w][tp]);
-    };
-    auto record = [&](int w, uint32_t cell) -> int4 {              // the same for a wave-uniform cell (scalar control flow)
-        return record_of(w, __builtin_amdgcn_readfirstlane(cell));
-    };
+    // the records themselves, once per workgroup: the groups read them back with one ds_read_b128 each
+    __shared__ int4 hrec[2][kHeadsMax];
     {
         const uint32_t w = threadIdx.x >> 6, t = threadIdx.x & 63u;
         if (w < 2u && t < n_cell[w]) {
             const uint32_t cell = cell_lo[w] + t;
+            int4 r;
+            if (cell + 1u < cells_total) r = make_int4(hc[w][t], hs[w][t], hc[w][t + 1] - hc[w][t], hs[w][t + 1] - hs[w][t]);
+            else {
+                const uint32_t tp = t ? t - 1u : n_cell[w] + 1u;     // last cell of the table: slope of the cell before it
+                r = make_int4(hc[w][t], hs[w][t], hc[w][t] - hc[w][tp], hs[w][t] - hs[w][tp]);
+            }
+            hrec[w][t] = r;
             if ((cell << d) >= r_lo[w])                              // its first entry is stored by this workgroup
-                reinterpret_cast<int4 *>(const_cast<void *>(plan.tab_coarse))[cell] = record_of((int)w, cell);
+                reinterpret_cast<int4 *>(const_cast<void *>(plan.tab_coarse))[cell] = r;
         }
     }
+    __syncthreads();
+    auto record_of = [&](int w, uint32_t cell) -> int4 { return hrec[w][cell - cell_lo[w]]; };   // cell in [cell_lo[w], cell_lo[w] + n_cell[w])
+    auto record = [&](int w, uint32_t cell) -> int4 {              // the same for a wave-uniform cell (a broadcast read)
+        return record_of(w, __builtin_amdgcn_readfirstlane(cell));
+    };
 
     // one entry: deviation from the record's straight line, checked and packed
     auto store_entry = [&](uint32_t idx, int32_t c, int32_t sn, const int4 rec, uint32_t pos) {
@@ -767,7 +777,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
     };
 
     // ---- phase 2: one wave per group, one lane per leaf (and its image) ----
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;   // g and the cell arithmetic below stay scalar
     // index of leaf (g, lane) = idx_a + g * idx_m; index of its image E - u = idx_i - (that) -- split layout per residue class of the lane
     uint32_t idx_a, idx_m, idx_i;
     if (lane & 1u)      { idx_a = (E >> 1) + (lane >> 1); idx_m = 32u; idx_i = E + (E >> 1) - 1u; }
@@ -776,12 +786,12 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
     if (!plan.tab_split) { idx_a = lane; idx_m = 64u; idx_i = E; }  // natural layout (nibble tables): index u, image E - u
     const uint32_t fmask = (1u << d) - 1u;
     for (uint32_t gi = wave; gi < gpw; gi += kBuildThreads / 64) {
-        const uint32_t g = group0 + gi;
+        const uint32_t g = __builtin_amdgcn_readfirstlane(group0 + gi);   // (kept in a vector register otherwise, and the cell arithmetic with it)
         if (g >= n_groups) break;
         int64_t x = gx[gi], y = gy[gi];
         int32_t z = (int32_t)((uint32_t)gz[gi] + (lane << s));
-        const int32_t z_start = z;
         const int k0 = __builtin_amdgcn_readfirstlane(gk[gi]);
+        const uint32_t gf = __builtin_amdgcn_readfirstlane(gflag[gi]);
         uint64_t zmask = 0ull;                                       // lanes whose z_k was exactly 0 at a rotation before KS
 #pragma unroll
         for (int k = 1; k < KS; ++k) {
@@ -816,7 +826,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
         const uint32_t idx = idx_a + g * idx_m;
         store_entry(idx, (int32_t)(x >> plan.out_shr), (int32_t)(y >> plan.out_shr), record(0, (g << 6) >> d), ((g << 6) & fmask) + lane);
         int32_t c2 = (int32_t)(x2 >> plan.out_shr), s2 = (int32_t)(y2 >> plan.out_shr);
-        if (lane == 0u && u >= 1u && u <= m_last && gflag[gi]) {      // rare: the shared prefix is not mirrored for leaf 0
+        if (gf != 0u && lane == 0u && u >= 1u && u <= m_last) {       // rare (scalar test first): the shared prefix is not mirrored for leaf 0
             int64_t xf = plan.x0, yf = plan.x0;
             int32_t zf = (int32_t)(((E - u) << s) - lut_s[0]);
 #pragma unroll 1
@@ -2112,7 +2122,7 @@ __global__ __launch_bounds__(kRlBlock) void k_runlength_window(BhwCordicCfg cfg,
     const uint32_t lq = cfg.phi_width - 2;
     const uint32_t E = 1u << lq, emask = E - 1u, H = E >> 1;
     const uint32_t W = cfg.dat_width, zs = cfg.z_shr, zmask = (1u << zs) - 1u;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t r_wave = (blockIdx.x * kRlBlock + (wave << 6)) * kRlRun;     // first ring lane of this wave's 1024
     const uint32_t r0 = r_wave + lane * kRlRun;
     constexpr uint32_t R1 = kRlRun - 1;
@@ -3296,7 +3306,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_prerot_sweep(BhwPrerotCfg c, 
         gx[threadIdx.x] = x; gy[threadIdx.x] = y; gz[threadIdx.x] = zf; gk[threadIdx.x] = k;
     }
     __syncthreads();
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     const uint32_t nmask = (1u << PW) - 1u;                                  // PW <= 32 here: a sweep of 2^PW phases in int32 indices
     for (uint32_t gi = wave; gi < (uint32_t)kGroupsPerWg; gi += kBuildThreads / 64) {
         const uint32_t g = group0 + gi;
