@@ -822,9 +822,11 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
             rot_step(x, y, z, k, plan.lut[k]);
             rot_step(x2, y2, z2, k, plan.lut[k]);
         }
-        const uint32_t u = (g << 6) + lane;
+        const uint32_t g6 = __builtin_amdgcn_readfirstlane(g << 6);   // back in a scalar register (merged with the zero-event path's copy it
+                                                                      // lands in a vector one, and the wave-uniform cell arithmetic below with it)
+        const uint32_t u = g6 + lane;
         const uint32_t idx = idx_a + g * idx_m;
-        store_entry(idx, (int32_t)(x >> plan.out_shr), (int32_t)(y >> plan.out_shr), record(0, (g << 6) >> d), ((g << 6) & fmask) + lane);
+        store_entry(idx, (int32_t)(x >> plan.out_shr), (int32_t)(y >> plan.out_shr), record(0, g6 >> d), (g6 & fmask) + lane);
         int32_t c2 = (int32_t)(x2 >> plan.out_shr), s2 = (int32_t)(y2 >> plan.out_shr);
         if (gf != 0u && lane == 0u && u >= 1u && u <= m_last) {       // rare (scalar test first): the shared prefix is not mirrored for leaf 0
             int64_t xf = plan.x0, yf = plan.x0;
@@ -837,7 +839,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
         if (u >= 1u && u <= m_last && !deferred) {
             // images E - 64g - 63 .. E - 64g, descending with the lane: one cell, or two when lane 0's image opens the next one
             const uint32_t um = E - u;
-            const uint32_t top = E - (g << 6), cell_a = (top - 63u) >> d, cell_b = top >> d;       // wave-uniform
+            const uint32_t top = E - g6, cell_a = (top - 63u) >> d, cell_b = top >> d;             // wave-uniform
             const uint32_t cell_c = cell_a >= cell_lo[1] ? cell_a : cell_lo[1];                      // (sources above m_last are masked off)
             int4 rec2 = record(1, cell_c);
             if (__builtin_amdgcn_readfirstlane(cell_b) != __builtin_amdgcn_readfirstlane(cell_c)) { // scalar branch, 1 group in 2^(d-6)
