@@ -96,7 +96,7 @@ def cpu_baseline(target_seconds=12.0, max_threads=16):
 def sources_sha16():
     """sha256 prefix of the kernel + ABI sources: ties a committed PMC summary to the code it was measured on."""
     h = hashlib.sha256()
-    for f in ("bhw_kernels.hip", "bhw_api.cpp", "bhw_internal.h"):
+    for f in ("bhw_device.h", "bhw_build.hip", "bhw_combine.hip", "bhw_direct.hip", "bhw_fused.hip", "bhw_api.cpp", "bhw_internal.h"):
         with open(os.path.join(ROOT, "blackman_harris_win_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

@@ -63,22 +63,47 @@ def _write_stamp(target, digest):
         f.write(digest + "\n")
 
 
-def build_library(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, f) for f in ("bhw_api.cpp", "bhw_kernels.hip", "bhw_rom.c", "bhw_internal.h", "bhw_tables.inc")]
+KERNEL_UNITS = ("bhw_direct.hip", "bhw_build.hip", "bhw_combine.hip", "bhw_fused.hip", "bhw_taylor.hip", "bhw_variants.hip")
+HEADERS = ("bhw_internal.h", "bhw_device.h", "bhw_tables.inc")
+
+
+def library_sources():
+    srcs = [os.path.join(CSRC, f) for f in ("bhw_api.cpp", "bhw_rom.c") + KERNEL_UNITS + HEADERS]
     srcs.append(os.path.join(ROOT, "include", "bhw.h"))
-    digest = _digest(srcs, os.environ.get("BHW_EXTRA_FLAGS", ""))
+    return srcs
+
+
+def compile_units(objdir, flags=(), jobs=None):
+    """hipcc -c of every translation unit (in parallel), gcc -c of the ROM generator; returns (objects, compiler output)."""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = _hipcc()
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+            "-Rpass-analysis=kernel-resource-usage"] + list(flags)
+    jobsl = []
+    for unit in ("bhw_api.cpp",) + KERNEL_UNITS:
+        obj = os.path.join(objdir, os.path.splitext(unit)[0] + ".o")
+        jobsl.append((obj, base + ["-x", "hip", "-c", os.path.join(CSRC, unit), "-o", obj]))
+    rom_o = os.path.join(objdir, "bhw_rom.o")
+    jobsl.append((rom_o, ["gcc", "-O2", "-fPIC", "-c", os.path.join(CSRC, "bhw_rom.c"), "-o", rom_o]))
+    with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
+        outs = list(ex.map(lambda j: _run(j[1]), jobsl))
+    return [j[0] for j in jobsl], "\n".join(outs)
+
+
+def link_library(objects, out):
+    quad = subprocess.run(["gcc", "-print-file-name=libquadmath.so"], stdout=subprocess.PIPE, text=True).stdout.strip()
+    _run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + list(objects) +
+         [quad, "-Wl,-rpath," + os.path.dirname(os.path.realpath(quad)), "-o", out])
+
+
+def build_library(force=False, verbose=False):
+    extra = os.environ.get("BHW_EXTRA_FLAGS", "")
+    digest = _digest(library_sources(), extra)
     if not force and _stamp_ok(LIB, digest):
         return LIB
-    rom_o = os.path.join(CSRC, "bhw_rom.o")
-    _run(["gcc", "-O2", "-fPIC", "-c", os.path.join(CSRC, "bhw_rom.c"), "-o", rom_o])
-    quad = subprocess.run(["gcc", "-print-file-name=libquadmath.so"], stdout=subprocess.PIPE, text=True).stdout.strip()
-    extra = os.environ.get("BHW_EXTRA_FLAGS", "").split()
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage"] + extra + ["-x", "hip",
-           os.path.join(CSRC, "bhw_api.cpp"), os.path.join(CSRC, "bhw_kernels.hip"),
-           "-x", "none", rom_o, quad, "-Wl,-rpath," + os.path.dirname(os.path.realpath(quad)),
-           "-o", LIB]
-    out = _run(cmd)
+    objects, out = compile_units(os.path.join(ROOT, "build", "obj"), extra.split())
+    link_library(objects, LIB)
     _write_resources(out)
     _write_stamp(LIB, digest)
     if verbose and out:

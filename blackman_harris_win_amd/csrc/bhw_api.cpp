@@ -519,7 +519,7 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
     const bool images = !has_period && bhwk_tile_images_applicable(c, w_probe, n0, count, &img_mask, &n0mod);
     const bool tiled = (has_period && bhwk_tile_applicable(c, w)) || images;
     c.tab_split = (tiled && c.z_shr == 0) ? 1u : 0u;
-    // whole-period tile tables are stored packed when the widths allow it (formats in bhw_kernels.hip): "residual" = 2 bytes per
+    // whole-period tile tables are stored packed when the widths allow it (formats in bhw_device.h): "residual" = 2 bytes per
     // entry + one int4 record per 2^d entries, else "delta16" = 4 bytes per entry + one int2 head per 64 entries, else the plain
     // 8 bytes per entry.  The combine pass is bound by table + output traffic as much as by arithmetic.
     rc = build_table(p, l, c, tiled, exec_table_format(ex), ws);

@@ -1,0 +1,606 @@
+// bhw_build.hip -- table strategy, pass 1: the first-quadrant (c, s) table
+//
+// Part of the hand-written HIP kernels for gfx950 (MI355X, CDNA4) behind include/bhw.h.  Hot path of the reference: phase
+// accumulator -> CORDIC rotation chain (or Taylor LUT) -> weighted N-term cosine sum -> int32 coefficient (SURVEY section 8a
+// rows a1-a11).  Integer semantics follow SURVEY App. A; reference lines are cited at each step.
+#include "bhw_device.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// Table strategy, pass 1: first-quadrant (c, s) for every distinct CORDIC input
+//   u in [0, 2^(PW-2-z_shr)),  z0 = u << z_shl.
+// Every harmonic of every coefficient evaluates this same function (the quadrant field is
+// applied after the rotation), so the whole window needs only 2^(PW-2-z_shr) chains.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_table_build(BhwCordicCfg cfg, uint32_t entries, void *__restrict__ table)
+{
+    __shared__ T lut_s[32];
+    stage_lut<T>(cfg, lut_s);
+    const uint32_t u = blockIdx.x * kBlock + threadIdx.x;
+    if (u >= entries) return;
+    T x, y;
+    cordic_q1<T>(lut_s, (T)cfg.x0, (T)((T)u << cfg.z_shl), (int)cfg.n_iter, x, y);
+    const int32_t c = (int32_t)(x >> cfg.out_shr), sn = (int32_t)(y >> cfg.out_shr);
+    // a wave holds one aligned 64-entry block (the packed format needs entries >= 64, see bhwk_packed_ok)
+    const int2 head = make_int2(__builtin_amdgcn_readfirstlane(c), __builtin_amdgcn_readfirstlane(sn));
+    const int4 rec = cfg.tab_dlog > kPackLog ? reinterpret_cast<const int4 *>(cfg.tab_coarse)[u >> fmt_cell_log(cfg.tab_dlog)] : make_int4(0, 0, 0, 0);
+    tab_store(table, u, cfg.phi_width - 2 - cfg.z_shr, cfg.tab_split, cfg.tab_dlog, const_cast<void *>(cfg.tab_coarse), c, sn, head, rec,
+              cfg.tab_check);
+}
+
+// ---------------------------------------------------------------------------------------
+// Table strategy, pass 1, shared-prefix form.
+//
+// Leaves u (table entries) are contiguous in angle: z0(u) = u << z_shl.  At rotation k every leaf of
+// a group takes the same decision as long as sign(z_k) agrees at the group's two end leaves (z_k is
+// the same affine function of u for all of them), and then (x_k, y_k) is one value for the group.
+//   phase 1: one lane per group of 64 leaves runs the chain from k = 1 until the first rotation at
+//            which the group's end leaves disagree (or kPrefixMax), and parks (x, y, z_first, k) in LDS;
+//   phase 2: each wave takes a group, broadcasts the parked state, and runs only the remaining
+//            rotations with one lane per leaf.
+// Rotation step in "mad" form (x, y 64-bit; z 32-bit; sg = +1 / -1 = the decision):
+//   x += (-sg) * lo32(y >> k);  y += sg * lo32(x >> k)      -> v_ashrrev_i64 / v_mad_i64_i32
+//   z += (-sg) * lut[k]                                       -> v_mad_i32_i24 once lut[k] < 2^23
+// Valid when |x|,|y| < 2^33 and the quarter circle <= 2^32 (all models at W <= 32; VHDL: W+P <= 34):
+// rotation 0 always adds (z0 >= 0), giving x1 = y1 = x0 and z1 = z0 - lut[0], which fits int32.
+// ---------------------------------------------------------------------------------------
+
+// FMT: table format as a template parameter (0 plain, 1 delta16, 2 residual): no format branches around the stores.
+template <int NITER, int FMT>
+__global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPlan plan, void *__restrict__ table)
+{
+    __shared__ int64_t gx[kGroupsPerWg];
+    __shared__ int64_t gy[kGroupsPerWg];
+    __shared__ int32_t gz[kGroupsPerWg];
+    __shared__ int32_t gk[kGroupsPerWg];
+    __shared__ uint32_t lut_s[32];
+    if (threadIdx.x < 32) lut_s[threadIdx.x] = plan.lut[threadIdx.x];
+    __syncthreads();
+
+    constexpr int n_iter = NITER;
+    const uint32_t s = plan.z_shl;
+    const uint32_t gpw = plan.groups_per_wg;
+    const uint32_t group0 = blockIdx.x * gpw;
+    const uint32_t n_groups = plan.entries >> 6;
+
+    // Residual format: the records {c, s, dc, ds} of the cells this workgroup touches.  Lanes of the second wave run the full
+    // chain (the very rot_step of the leaves) at the cell starts -- heads cell_lo .. cell_lo + n_cell, plus head cell_lo - 1
+    // for the table's last cell, whose end point is not an entry and which reuses the slope of the cell before it -- while
+    // the first wave runs the group prefixes; cells that start inside this workgroup are also written out for the combine pass.
+    __shared__ int32_t hc[kHeadsMax], hs[kHeadsMax];
+    const uint32_t d = fmt_cell_log(plan.tab_dlog);
+    constexpr bool resid = (FMT == 2 || FMT == 3);            // (FMT 4: no table, see the store below)
+    const uint32_t cells_total = resid ? plan.entries >> d : 0u;
+    uint32_t cell_lo = 0, n_cell = 0;
+    if (resid) {
+        const uint32_t u_end = ((group0 + gpw) << 6) < plan.entries ? ((group0 + gpw) << 6) : plan.entries;
+        cell_lo = (group0 << 6) >> d;
+        n_cell = ((u_end - 1u) >> d) - cell_lo + 1u;
+    }
+    if (resid && threadIdx.x >= 64u && threadIdx.x < 64u + n_cell + 2u) {
+        const uint32_t t = threadIdx.x - 64u;
+        const int64_t cell = (t <= n_cell) ? (int64_t)cell_lo + t : (int64_t)cell_lo - 1;
+        if (cell >= 0 && cell < (int64_t)cells_total) {
+            int64_t x = plan.x0, y = plan.x0;
+            int32_t z = (int32_t)((((uint32_t)cell << d) << s) - lut_s[0]);
+#pragma unroll
+            for (int r = 1; r < n_iter; ++r) rot_step(x, y, z, r, plan.lut[r]);
+            hc[t] = (int32_t)(x >> plan.out_shr);
+            hs[t] = (int32_t)(y >> plan.out_shr);
+        }
+    }
+
+    // ---- phase 1: shared prefix of each 64-leaf group ----
+    if (threadIdx.x < gpw) {
+        const uint32_t g = group0 + threadIdx.x;
+        const uint32_t u_first = g << 6;
+        int64_t x = plan.x0, y = plan.x0;                                        // after rotation 0
+        int32_t zf = (int32_t)((u_first << s) - lut_s[0]);
+        const uint32_t span = 63u << s;                                          // z_last - z_first
+        int k = 1;
+        bool live = g < n_groups;
+        // unrolled: immediate shifts and scalar ROM words; this serial chain is the latency every workgroup starts with
+        constexpr int kmax = n_iter < kPrefixMax ? n_iter : kPrefixMax;
+#pragma unroll
+        for (int kk = 1; kk < kmax; ++kk) {
+            if (live) {
+                const int32_t zl = (int32_t)((uint32_t)zf + span);
+                if ((zf < 0) != (zl < 0)) {
+                    live = false;                                                // the group splits at rotation kk
+                } else {
+                    rot_step(x, y, zf, kk, plan.lut[kk]);
+                    k = kk + 1;
+                }
+            }
+        }
+        gx[threadIdx.x] = x;
+        gy[threadIdx.x] = y;
+        gz[threadIdx.x] = zf;
+        gk[threadIdx.x] = k;
+    }
+    __syncthreads();
+
+    auto record_of = [&](uint32_t cell) -> int4 {                  // cell in [cell_lo, cell_lo + n_cell)
+        const uint32_t t = cell - cell_lo;
+        if (cell + 1u < cells_total) return make_int4(hc[t], hs[t], hc[t + 1] - hc[t], hs[t + 1] - hs[t]);
+        const uint32_t tp = t ? t - 1u : n_cell + 1u;                // last cell of the table: slope of the cell before it
+        return make_int4(hc[t], hs[t], hc[t] - hc[tp], hs[t] - hs[tp]);
+    };
+    auto record = [&](uint32_t cell) -> int4 {                     // the same for a wave-uniform cell: scalar control flow
+        return record_of(__builtin_amdgcn_readfirstlane(cell));
+    };
+    if (resid && threadIdx.x < n_cell) {
+        const uint32_t cell = cell_lo + threadIdx.x;
+        if ((cell << d) >= (group0 << 6))                            // starts inside this workgroup's entries: this one writes it
+            reinterpret_cast<int4 *>(const_cast<void *>(plan.tab_coarse))[cell] = record_of(cell);
+    }
+
+    // ---- phase 2: one wave per group, one lane per leaf, remaining rotations only ----
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;   // g and what derives from it stay scalar
+    // table index of leaf (g, lane) = idx_a + g * idx_m: natural layout 64 g + lane; split layout per residue class of the lane
+    // (64 g + lane has the lane's residue mod 4), tab_index() folded into two per-lane constants
+    uint32_t idx_a = lane, idx_m = 64u;
+    if (plan.tab_split) {
+        const uint32_t e = 1u << plan.log2_entries;
+        if (lane & 1u)      { idx_a = (e >> 1) + (lane >> 1); idx_m = 32u; }
+        else if (lane & 2u) { idx_a = (e >> 2) + (lane >> 2); idx_m = 16u; }
+        else                { idx_a = lane >> 2;              idx_m = 16u; }
+    }
+    for (uint32_t gi = wave; gi < gpw; gi += kBuildThreads / 64) {
+        const uint32_t g = __builtin_amdgcn_readfirstlane(group0 + gi);
+        if (g >= n_groups) break;
+        int64_t x = gx[gi], y = gy[gi];
+        int32_t z = (int32_t)((uint32_t)gz[gi] + (lane << s));
+        const int k0 = __builtin_amdgcn_readfirstlane(gk[gi]);
+        // Fully unrolled: every shift is an immediate and every lut entry a scalar kernel argument; k0 is
+        // wave-uniform, so each guard is one scalar compare-and-branch.
+#pragma unroll
+        for (int k = 1; k < NITER; ++k) {
+            if (k >= kPrefixMax || k >= k0) rot_step(x, y, z, k, plan.lut[k]);   // k0 <= kPrefixMax: no guard (one basic block) beyond it
+        }
+        const int32_t c = (int32_t)(x >> plan.out_shr), sn = (int32_t)(y >> plan.out_shr);
+        const int2 head = make_int2(__builtin_amdgcn_readfirstlane(c), __builtin_amdgcn_readfirstlane(sn));   // leaf 0 of the group
+        const uint32_t idx = idx_a + g * idx_m;
+        if constexpr (FMT == 4) {
+            // sin / cos sweep over one whole period (bhwk_sincos): no table -- the leaf's first-quadrant pair goes out as its four
+            // quadrant images, phase q*E + u at stream position (phase - theta0) mod N.  table = d_sin, tab_coarse = d_cos (either
+            // may be NULL), pad0 = the model's negation rule, pad = theta0 mod N.
+            const uint32_t u = (g << 6) + lane, nmask = 4u * plan.entries - 1u;
+            int32_t *d_sin = reinterpret_cast<int32_t *>(table), *d_cos = reinterpret_cast<int32_t *>(const_cast<void *>(plan.tab_coarse));
+#pragma unroll
+            for (uint32_t q = 0; q < 4u; ++q) {
+                int32_t oc, os;
+                quadrant_map(q, c, sn, plan.pad0, oc, os);
+                const uint32_t i = (q * plan.entries + u - plan.pad) & nmask;
+                if (d_sin) d_sin[i] = os;
+                if (d_cos) d_cos[i] = oc;
+            }
+        } else if constexpr (FMT == 0) {
+            reinterpret_cast<int2 *>(table)[idx] = make_int2(c, sn);
+        } else if constexpr (FMT == 1) {
+            const int32_t dc = c - head.x, ds = sn - head.y;
+            if (plan.check_flag && !(fits_bits(dc, 16) && fits_bits(ds, 16))) atomicOr(plan.check_flag, 1u);   // scalar guard: verified configurations skip it
+            reinterpret_cast<uint32_t *>(table)[idx] = ((uint32_t)dc & 0xFFFFu) | ((uint32_t)ds << 16);
+            if (lane == 0u) reinterpret_cast<int2 *>(const_cast<void *>(plan.tab_coarse))[g] = head;   // block = group
+        } else {
+            const int4 rec = record((g << 6) >> d);                                                     // wave-uniform
+            const int2 p = tab_predict(rec, ((g << 6) & ((1u << d) - 1u)) + lane, d);
+            const int32_t dc = c - p.x, ds = sn - p.y;
+            // (byte-wide stores make this variant 2 % slower than the two-byte one at equal instruction counts, 72.3 against 70.7 us;
+            // staging a workgroup's entries in shared memory and writing them as 16-byte packets costs more than it saves, +1.5 us)
+            if constexpr (FMT == 3) {
+                if (plan.check_flag && !(fits_bits(dc, 4) && fits_bits(ds, 4))) atomicOr(plan.check_flag, 1u);
+                reinterpret_cast<uint8_t *>(table)[idx] = (uint8_t)(((uint32_t)dc & 0xFu) | (((uint32_t)ds & 0xFu) << 4));
+            } else {
+                if (plan.check_flag && !(fits_bits(dc, 8) && fits_bits(ds, 8))) atomicOr(plan.check_flag, 1u);
+                reinterpret_cast<uint16_t *>(table)[idx] = (uint16_t)(((uint32_t)dc & 0xFFu) | (((uint32_t)ds & 0xFFu) << 8));
+            }
+        }
+    }
+}
+
+// Table strategy, pass 1, octant-mirror form (residual / nibble formats in the split layout).
+//
+// After rotation 0 the state is the 45-degree vector (x0, x0) and 2 * lut[0] is exactly a quarter turn (checked by the launcher),
+// so the chain of u' = E - u is the chain of u with x and y swapped, z negated and every decision flipped -- bit for bit, floors
+// included -- as long as no z_k on the way is exactly 0 (z >= 0 rotates forward in both).  Zero events are common only in the last
+// rotations (|z| is a few units there), so:
+//   * only u in [0, E/2) run a chain of their own; u' in (E/2, E) are images of u in [1, E/2 - 1]; the middle entry E/2 is a
+//     deferred chain of the last workgroup;
+//   * at rotation KS = NITER - kMirrorTail the image state is taken as (y, x, -z) and the last rotations run for both;
+//   * a lane that met z_k == 0 before KS (one v_cmp per shared rotation, collected in a scalar mask; about 1 % of the lanes, but
+//     every second wave has one) does not store its image: it appends u to a worklist in shared memory, and after the groups
+//     the workgroup's first lanes run those images as chains of their own (a wave-wide replay in place costs more than the
+//     symmetry saves);
+//   * a group whose shared prefix itself met z == 0 (only its leaf 0 can) recomputes that one image from scratch;
+//   * the records of the image cells come from chains of their own (third wave), never from the symmetry.
+// Per pair of entries 9 shared + 2 x 6 own rotations instead of 2 x 15.
+constexpr int kMirrorTail = 6;         // rotations run separately for an entry and its image (tails of 5 or 7 measured slower)
+constexpr int kMirrorGpw = 64;         // own groups per workgroup
+template <int NITER, int FMT>
+__global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPlan plan, void *__restrict__ table)
+{
+    static_assert(FMT == 2 || FMT == 3, "residual / nibble entries");
+    __shared__ int64_t gx[kGroupsPerWg];
+    __shared__ int64_t gy[kGroupsPerWg];
+    __shared__ int32_t gz[kGroupsPerWg];
+    __shared__ int32_t gk[kGroupsPerWg];
+    __shared__ uint32_t gflag[kGroupsPerWg];
+    __shared__ uint32_t lut_s[32];
+    constexpr uint32_t kWorkMax = 512;               // images to run as chains of their own (expected ~40 per workgroup)
+    __shared__ uint32_t work_n;
+    __shared__ uint32_t work_u[kWorkMax];
+    if (threadIdx.x < 32) lut_s[threadIdx.x] = plan.lut[threadIdx.x];
+    constexpr int n_iter = NITER;
+    constexpr int KS = NITER - kMirrorTail;                     // image state taken at this rotation
+    const uint32_t s = plan.z_shl;
+    constexpr uint32_t gpw = kMirrorGpw;                        // own groups per workgroup
+    const uint32_t group0 = blockIdx.x * gpw;
+    const uint32_t E = plan.entries;
+    const uint32_t n_groups = E >> 7;   // groups that run chains of their own
+    const uint32_t u_lo = group0 << 6;
+    const uint32_t u_hi = ((group0 + gpw) << 6) < (n_groups << 6) ? ((group0 + gpw) << 6) : (n_groups << 6);   // own entries [u_lo, u_hi)
+    const uint32_t m_last = (E >> 1) - 1u;    // u in [1, m_last] also produce the image E - u
+    if (threadIdx.x == 0) {
+        work_n = 0u;
+        if (u_hi == (E >> 1)) {                  // the middle entry E/2 (its own image): one more deferred chain
+            work_u[0] = E >> 1;
+            work_n = 1u;
+        }
+    }
+    __syncthreads();
+
+
+    // records {c, s, dc, ds} of the cells this workgroup stores into: w = 0 its own range, w = 1 the image range.  Heads
+    // lo .. lo + n, plus head lo - 1 for the table's last cell (see k_table_build_shared), by full chains of the second / third wave.
+    __shared__ int32_t hc[2][kHeadsMax], hs[2][kHeadsMax];
+    const uint32_t d = fmt_cell_log(plan.tab_dlog);
+    const uint32_t cells_total = E >> d;
+    uint32_t cell_lo[2] = {0u, 0u}, n_cell[2] = {0u, 0u}, r_lo[2] = {u_lo, 0u}, r_hi[2] = {u_hi, 0u};   // entry ranges [r_lo, r_hi)
+    {
+        const uint32_t a = u_lo > 1u ? u_lo : 1u, b = (u_hi - 1u) < m_last ? (u_hi - 1u) : m_last;        // sources a .. b
+        if (a <= b) { r_lo[1] = E - b; r_hi[1] = E - a + 1u; }
+        if (a <= b && b == (E >> 1) - 1u) r_lo[1] = E >> 1;      // the middle entry belongs to this image range
+    }
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+        if (r_hi[w] > r_lo[w]) {
+            cell_lo[w] = r_lo[w] >> d;
+            n_cell[w] = ((r_hi[w] - 1u) >> d) - cell_lo[w] + 1u;
+        }
+    {
+        const uint32_t w = (threadIdx.x >> 6) - 1u;                  // wave 1 -> own range, wave 2 -> image range
+        const uint32_t t = threadIdx.x & 63u;
+        if (w < 2u && n_cell[w] && t < n_cell[w] + 2u) {
+            const int64_t cell = (t <= n_cell[w]) ? (int64_t)cell_lo[w] + t : (int64_t)cell_lo[w] - 1;
+            if (cell >= 0 && cell < (int64_t)cells_total) {
+                int64_t x = plan.x0, y = plan.x0;
+                int32_t z = (int32_t)((((uint32_t)cell << d) << s) - lut_s[0]);
+#pragma unroll
+                for (int r = 1; r < n_iter; ++r) rot_step(x, y, z, r, plan.lut[r]);
+                hc[w][t] = (int32_t)(x >> plan.out_shr);
+                hs[w][t] = (int32_t)(y >> plan.out_shr);
+            }
+        }
+    }
+
+    // ---- phase 1: shared prefix of each 64-leaf group (never past KS: the image state is taken there) ----
+    constexpr int kcap = KS < kPrefixMax ? KS : kPrefixMax;
+    if (threadIdx.x < gpw) {
+        const uint32_t g = group0 + threadIdx.x;
+        const uint32_t u_first = g << 6;
+        int64_t x = plan.x0, y = plan.x0;                                        // after rotation 0
+        int32_t zf = (int32_t)((u_first << s) - lut_s[0]);
+        const uint32_t span = 63u << s;                                          // z_last - z_first
+        int k = 1;
+        bool live = g < n_groups;
+        uint32_t zero0 = 0u;                                                     // leaf 0 met z == 0 inside the shared prefix
+#pragma unroll
+        for (int kk = 1; kk < kcap; ++kk) {
+            if (live) {
+                const int32_t zl = (int32_t)((uint32_t)zf + span);
+                if ((zf < 0) != (zl < 0)) {
+                    live = false;                                                // the group splits at rotation kk
+                } else {
+                    zero0 |= (uint32_t)(zf == 0);
+                    rot_step(x, y, zf, kk, plan.lut[kk]);
+                    k = kk + 1;
+                }
+            }
+        }
+        gx[threadIdx.x] = x;
+        gy[threadIdx.x] = y;
+        gz[threadIdx.x] = zf;
+        gk[threadIdx.x] = k;
+        gflag[threadIdx.x] = zero0;
+    }
+    __syncthreads();
+
+    // the records themselves, once per workgroup: the groups read them back with one ds_read_b128 each
+    __shared__ int4 hrec[2][kHeadsMax];
+    {
+        const uint32_t w = threadIdx.x >> 6, t = threadIdx.x & 63u;
+        if (w < 2u && t < n_cell[w]) {
+            const uint32_t cell = cell_lo[w] + t;
+            int4 r;
+            if (cell + 1u < cells_total) r = make_int4(hc[w][t], hs[w][t], hc[w][t + 1] - hc[w][t], hs[w][t + 1] - hs[w][t]);
+            else {
+                const uint32_t tp = t ? t - 1u : n_cell[w] + 1u;     // last cell of the table: slope of the cell before it
+                r = make_int4(hc[w][t], hs[w][t], hc[w][t] - hc[w][tp], hs[w][t] - hs[w][tp]);
+            }
+            hrec[w][t] = r;
+            if ((cell << d) >= r_lo[w])                              // its first entry is stored by this workgroup
+                reinterpret_cast<int4 *>(const_cast<void *>(plan.tab_coarse))[cell] = r;
+        }
+    }
+    __syncthreads();
+    auto record_of = [&](int w, uint32_t cell) -> int4 { return hrec[w][cell - cell_lo[w]]; };   // cell in [cell_lo[w], cell_lo[w] + n_cell[w])
+    auto record = [&](int w, uint32_t cell) -> int4 {              // the same for a wave-uniform cell (a broadcast read)
+        return record_of(w, __builtin_amdgcn_readfirstlane(cell));
+    };
+
+    // one entry: deviation from the record's straight line, checked and packed
+    auto store_entry = [&](uint32_t idx, int32_t c, int32_t sn, const int4 rec, uint32_t pos) {
+        const int2 p = tab_predict(rec, pos, d);
+        const int32_t dc = c - p.x, ds = sn - p.y;
+        if constexpr (FMT == 3) {
+            if (plan.check_flag && !(fits_bits(dc, 4) && fits_bits(ds, 4))) atomicOr(plan.check_flag, 1u);
+            reinterpret_cast<uint8_t *>(table)[idx] = (uint8_t)(((uint32_t)dc & 0xFu) | (((uint32_t)ds & 0xFu) << 4));
+        } else {
+            if (plan.check_flag && !(fits_bits(dc, 8) && fits_bits(ds, 8))) atomicOr(plan.check_flag, 1u);
+            reinterpret_cast<uint16_t *>(table)[idx] = (uint16_t)(((uint32_t)dc & 0xFFu) | (((uint32_t)ds & 0xFFu) << 8));
+        }
+    };
+
+    // ---- phase 2: one wave per group, one lane per leaf (and its image) ----
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;   // g and the cell arithmetic below stay scalar
+    // index of leaf (g, lane) = idx_a + g * idx_m; index of its image E - u = idx_i - (that) -- split layout per residue class of the lane
+    uint32_t idx_a, idx_m, idx_i;
+    if (lane & 1u)      { idx_a = (E >> 1) + (lane >> 1); idx_m = 32u; idx_i = E + (E >> 1) - 1u; }
+    else if (lane & 2u) { idx_a = (E >> 2) + (lane >> 2); idx_m = 16u; idx_i = (E >> 1) + (E >> 2) - 1u; }
+    else                { idx_a = lane >> 2;              idx_m = 16u; idx_i = E >> 2; }
+    if (!plan.tab_split) { idx_a = lane; idx_m = 64u; idx_i = E; }  // natural layout (nibble tables): index u, image E - u
+    const uint32_t fmask = (1u << d) - 1u;
+    for (uint32_t gi = wave; gi < gpw; gi += kBuildThreads / 64) {
+        const uint32_t g = __builtin_amdgcn_readfirstlane(group0 + gi);   // (kept in a vector register otherwise, and the cell arithmetic with it)
+        if (g >= n_groups) break;
+        int64_t x = gx[gi], y = gy[gi];
+        int32_t z = (int32_t)((uint32_t)gz[gi] + (lane << s));
+        const int k0 = __builtin_amdgcn_readfirstlane(gk[gi]);
+        const uint32_t gf = __builtin_amdgcn_readfirstlane(gflag[gi]);
+        uint64_t zmask = 0ull;                                       // lanes whose z_k was exactly 0 at a rotation before KS
+#pragma unroll
+        for (int k = 1; k < KS; ++k) {
+            if (k >= kcap || k >= k0) {
+                zmask |= __builtin_amdgcn_ballot_w64(z == 0);
+                rot_step(x, y, z, k, plan.lut[k]);
+            }
+        }
+        int64_t x2 = y, y2 = x;                                      // image chain at rotation KS
+        int32_t z2 = -z;
+        bool deferred = false;                                       // this lane's image goes to the worklist
+        if (zmask != 0ull) {                                         // scalar
+            const uint32_t u_ = (g << 6) + lane;
+            if (((zmask >> lane) & 1ull) != 0ull && u_ >= 1u && u_ <= m_last) {
+                const uint32_t slot = atomicAdd(&work_n, 1u);
+                if (slot < kWorkMax) { work_u[slot] = u_; deferred = true; }
+                else {                                               // list full (never seen): the image chain from scratch, in place
+                    int64_t xf = plan.x0, yf = plan.x0;
+                    int32_t zf = (int32_t)(((E - u_) << s) - lut_s[0]);
+#pragma unroll 1
+                    for (int r = 1; r < KS; ++r) rot_step(xf, yf, zf, r, lut_s[r]);
+                    x2 = xf; y2 = yf; z2 = zf;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = KS; k < NITER; ++k) {
+            rot_step(x, y, z, k, plan.lut[k]);
+            rot_step(x2, y2, z2, k, plan.lut[k]);
+        }
+        const uint32_t g6 = __builtin_amdgcn_readfirstlane(g << 6);   // back in a scalar register (merged with the zero-event path's copy it
+                                                                      // lands in a vector one, and the wave-uniform cell arithmetic below with it)
+        const uint32_t u = g6 + lane;
+        const uint32_t idx = idx_a + g * idx_m;
+        store_entry(idx, (int32_t)(x >> plan.out_shr), (int32_t)(y >> plan.out_shr), record(0, g6 >> d), (g6 & fmask) + lane);
+        int32_t c2 = (int32_t)(x2 >> plan.out_shr), s2 = (int32_t)(y2 >> plan.out_shr);
+        if (gf != 0u && lane == 0u && u >= 1u && u <= m_last) {       // rare (scalar test first): the shared prefix is not mirrored for leaf 0
+            int64_t xf = plan.x0, yf = plan.x0;
+            int32_t zf = (int32_t)(((E - u) << s) - lut_s[0]);
+#pragma unroll 1
+            for (int r = 1; r < n_iter; ++r) rot_step(xf, yf, zf, r, lut_s[r]);
+            c2 = (int32_t)(xf >> plan.out_shr);
+            s2 = (int32_t)(yf >> plan.out_shr);
+        }
+        if (u >= 1u && u <= m_last && !deferred) {
+            // images E - 64g - 63 .. E - 64g, descending with the lane: one cell, or two when lane 0's image opens the next one
+            const uint32_t um = E - u;
+            const uint32_t top = E - g6, cell_a = (top - 63u) >> d, cell_b = top >> d;             // wave-uniform
+            const uint32_t cell_c = cell_a >= cell_lo[1] ? cell_a : cell_lo[1];                      // (sources above m_last are masked off)
+            int4 rec2 = record(1, cell_c);
+            if (__builtin_amdgcn_readfirstlane(cell_b) != __builtin_amdgcn_readfirstlane(cell_c)) { // scalar branch, 1 group in 2^(d-6)
+                const int4 rb = record(1, cell_b);
+                if (lane == 0u) rec2 = rb;
+            }
+            store_entry(idx_i - idx, c2, s2, rec2, um & fmask);
+        }
+    }
+    // ---- the deferred images: one lane each, the whole chain ----
+    __syncthreads();
+    const uint32_t n_work = work_n < kWorkMax ? work_n : kWorkMax;
+    for (uint32_t i = threadIdx.x; i < n_work; i += kBuildThreads) {
+        const uint32_t um = E - work_u[i];
+        int64_t xf = plan.x0, yf = plan.x0;
+        int32_t zf = (int32_t)((um << s) - lut_s[0]);
+#pragma unroll 1
+        for (int r = 1; r < n_iter; ++r) rot_step(xf, yf, zf, r, lut_s[r]);
+        store_entry(tab_index(um, plan.log2_entries, plan.tab_split), (int32_t)(xf >> plan.out_shr), (int32_t)(yf >> plan.out_shr), record_of(1, um >> d), um & fmask);
+    }
+}
+
+// Table strategy, pass 1, small tables: one lane per entry, the whole chain unrolled in the mad form, plain natural layout.
+// Below ~2^20 entries the shared-prefix kernel is bound by the latency of its serial prefix phase (8.3 us for 2^18 entries);
+// 64 independent chains per wave finish sooner.
+template <int NITER>
+__global__ __launch_bounds__(kBlock) void k_table_build_plain(BhwCordicCfg cfg, uint32_t entries, int2 *__restrict__ table)
+{
+    __shared__ uint32_t lut_s[32];
+    if (threadIdx.x < 32) lut_s[threadIdx.x] = (uint32_t)cfg.lut[threadIdx.x];
+    __syncthreads();
+    const uint32_t u = blockIdx.x * kBlock + threadIdx.x;
+    if (u >= entries) return;
+    int64_t x = cfg.x0, y = cfg.x0;                                              // rotation 0 always adds (z0 >= 0)
+    int32_t z = (int32_t)((u << cfg.z_shl) - lut_s[0]);
+#pragma unroll
+    for (int r = 1; r < NITER; ++r) rot_step(x, y, z, r, lut_s[r]);
+    table[u] = make_int2((int32_t)(x >> cfg.out_shr), (int32_t)(y >> cfg.out_shr));
+}
+
+} // namespace
+
+// Packed (delta16) table format applies when the (c, s) drift across a 64-entry block fits int16 with margin:
+// 63 * 2 pi * 2^(W-2-PW) + noise < 2^15  <=>  W - PW <= 8  (25.4 k at W - PW = 8).  Amplitude is 2^(W-2) for every model.
+bool bhwk_packed_ok(const BhwCordicCfg &c)
+{
+    if (c.z_shr != 0 || c.phi_width < 8) return false;
+    return (int)c.dat_width - (int)c.phi_width <= 8;
+}
+
+// Residual format: largest d <= 9 for which the straight line between records 2^d entries apart stays within half an LSB of
+// the true curve: (2 pi 2^d / 2^PW)^2 / 8 * 2^(W-2) <= 0.5.  0 = not applicable (d = 6 is left to delta16).
+uint32_t bhwk_resid_dlog(const BhwCordicCfg &c)
+{
+    if (c.z_shr != 0 || c.phi_width < 20 || c.dat_width + c.out_shr > 34 || c.n_iter < 7) return 0;
+    const int amp_bits = (int)c.dat_width - 2;                       // |c|, |s| <= 2^(W-2) (+1)
+    const int twice_d = 2 * (int)c.phi_width - amp_bits - 4;         // 4.93 * 2^(2d - 2PW + W - 2) <= 0.5
+    int d = twice_d / 2;
+    if (d > 9) d = 9;
+    if (d <= (int)kPackLog) return 0;                                // a 64-leaf build group must sit inside one cell
+    if ((int)c.phi_width - 2 - d < 2) return 0;
+    return (uint32_t)d;
+}
+
+// octant mirror (k_table_build_mirror): residual / nibble entries, tables of 2^20 entries and more, and the
+// exact quarter turn 2 * lut[0] == E << z_shl the symmetry rests on (true for every model at z_shr == 0; checked, not assumed)
+bool bhwk_build_mirror_applies(const BhwCordicCfg &c, uint32_t entries)
+{
+    const int fmt = fmt_of(c.tab_dlog);
+    return (fmt == 2 || fmt == 3) && (c.tab_split || fmt == 3) && c.z_shr == 0 && entries >= (1u << 20) && c.n_iter >= 21 &&
+           c.dat_width + c.out_shr <= 34 && 2ull * (uint64_t)(uint32_t)c.lut[0] == ((uint64_t)entries << c.z_shl);
+}
+
+// One whole period of cordic() (bhwk_sincos): the shared-prefix chains of the table build with the four quadrant images written
+// straight out (k_table_build_shared<N, 4>).
+int bhwk_sincos_sweep(const BhwLaunch &l, const BhwCordicCfg &c, uint64_t theta0, int32_t *d_sin, int32_t *d_cos)
+{
+    BHW_SET_DEVICE(l);
+    hipStream_t st = (hipStream_t)l.stream;
+    BhwBuildPlan plan;
+    for (uint32_t k = 0; k < 32; ++k) plan.lut[k] = (uint32_t)c.lut[k];
+    plan.entries = 1u << (c.phi_width - 2);
+    plan.n_iter = c.n_iter;
+    plan.z_shl = c.z_shl;
+    plan.out_shr = c.out_shr;
+    plan.log2_entries = c.phi_width - 2;
+    plan.tab_split = 0;
+    plan.tab_dlog = 0;
+    plan.pad0 = c.ones_neg;
+    plan.tab_coarse = d_cos;
+    plan.x0 = c.x0;
+    plan.check_flag = nullptr;
+    const unsigned groups = plan.entries >> 6;
+    plan.groups_per_wg = groups >= 64u * 1024u ? 64u : groups >= 16u * 1024u ? 16u : 4u;
+    plan.pad = (uint32_t)(theta0 & ((1ull << c.phi_width) - 1ull));
+    const dim3 grid((groups + plan.groups_per_wg - 1) / plan.groups_per_wg), block(kBuildThreads);
+    switch (c.n_iter) {
+#define BHW_CASE(N) case N: BHW_LAUNCH((k_table_build_shared<N, 4>), grid, block, 0, st, plan, (void *)d_sin); break;
+        BHW_CASE(7) BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14)
+        BHW_CASE(15) BHW_CASE(16) BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20) BHW_CASE(21) BHW_CASE(22)
+        BHW_CASE(23) BHW_CASE(24) BHW_CASE(25) BHW_CASE(26) BHW_CASE(27) BHW_CASE(28) BHW_CASE(29) BHW_CASE(30)
+        BHW_CASE(31) BHW_CASE(32)
+#undef BHW_CASE
+    default: return (int)hipErrorInvalidValue;
+    }
+    return finish(hipSuccess);
+}
+
+int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c_in, int32_t *d_table)
+{
+    const BhwCordicCfg c = table_layout(c_in);
+    BHW_SET_DEVICE(l);
+    hipStream_t st = (hipStream_t)l.stream;
+    const uint32_t entries = 1u << (c.phi_width - 2 - c.z_shr);
+    // shared-prefix kernel: needs whole 64-leaf groups, |x| < 2^33 and a quarter circle <= 2^32
+    const bool fits = (c.dat_width + c.out_shr <= 34);
+    if (fits && c.n_iter >= 7 && entries < (1u << 20) && c.tab_dlog == 0 && !c.tab_split) {
+        const dim3 grid(grid_for(entries)), block(kBlock);
+        switch (c.n_iter) {
+#define BHW_CASE(N) case N: BHW_LAUNCH(k_table_build_plain<N>, grid, block, 0, st, c, entries, (int2 *)d_table); break;
+            BHW_CASE(7) BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14)
+            BHW_CASE(15) BHW_CASE(16) BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20) BHW_CASE(21) BHW_CASE(22)
+            BHW_CASE(23) BHW_CASE(24) BHW_CASE(25) BHW_CASE(26) BHW_CASE(27) BHW_CASE(28) BHW_CASE(29) BHW_CASE(30)
+            BHW_CASE(31) BHW_CASE(32)
+#undef BHW_CASE
+        default: return (int)hipErrorInvalidValue;
+        }
+        return finish(hipSuccess);
+    }
+    if (entries >= 64 && fits && c.n_iter >= 2) {
+        BhwBuildPlan plan;
+        for (uint32_t k = 0; k < 32; ++k) plan.lut[k] = (uint32_t)c.lut[k];
+        plan.entries = entries;
+        plan.n_iter = c.n_iter;
+        plan.z_shl = c.z_shl;
+        plan.out_shr = c.out_shr;
+        plan.log2_entries = c.phi_width - 2 - c.z_shr;
+        plan.tab_split = c.tab_split;
+        plan.tab_dlog = c.tab_dlog;
+        plan.pad0 = 0;
+        plan.tab_coarse = c.tab_coarse;
+        plan.x0 = c.x0;
+        plan.check_flag = c.tab_check;
+        const unsigned groups = entries >> 6;
+        plan.groups_per_wg = groups >= 64u * 1024u ? 64u : groups >= 16u * 1024u ? 16u : 4u;
+        plan.pad = 0;
+        const dim3 grid((groups + plan.groups_per_wg - 1) / plan.groups_per_wg), block(kBuildThreads);
+        // plain tables for every rotation count; the packed formats (whole-period tile calls at z_shr == 0, i.e. PW >= 22 and
+        // therefore at least 21 rotations: the VHDL model at PW == W runs W - 1 of them) from 21 rotations on
+        const int fmt = fmt_of(c.tab_dlog);
+        if (c.n_iter < 21 && fmt != 0) return (int)hipErrorInvalidValue;
+        if (bhwk_build_mirror_applies(c, entries)) {
+            const unsigned own_groups = entries >> 7;
+            const dim3 mgrid((own_groups + kMirrorGpw - 1) / kMirrorGpw);
+            plan.groups_per_wg = kMirrorGpw;
+            switch (c.n_iter) {
+#define BHW_CASE_M(N) case N: if (fmt == 2) BHW_LAUNCH((k_table_build_mirror<N, 2>), mgrid, block, 0, st, plan, (void *)d_table); \
+                              else          BHW_LAUNCH((k_table_build_mirror<N, 3>), mgrid, block, 0, st, plan, (void *)d_table); break;
+                BHW_CASE_M(21) BHW_CASE_M(22) BHW_CASE_M(23) BHW_CASE_M(24) BHW_CASE_M(25) BHW_CASE_M(26) BHW_CASE_M(27) BHW_CASE_M(28)
+                BHW_CASE_M(29) BHW_CASE_M(30) BHW_CASE_M(31) BHW_CASE_M(32)
+#undef BHW_CASE_M
+            default: return (int)hipErrorInvalidValue;
+            }
+            return finish(hipSuccess);
+        }
+#define BHW_LAUNCH_BUILD(N, F) BHW_LAUNCH((k_table_build_shared<N, F>), grid, block, 0, st, plan, (void *)d_table)
+#define BHW_CASE(N) case N: BHW_LAUNCH_BUILD(N, 0); break;
+#define BHW_CASE_T(N) case N: if (fmt == 0) BHW_LAUNCH_BUILD(N, 0); else if (fmt == 1) BHW_LAUNCH_BUILD(N, 1); else if (fmt == 2) BHW_LAUNCH_BUILD(N, 2); else BHW_LAUNCH_BUILD(N, 3); break;
+        switch (c.n_iter) {
+            BHW_CASE(7) BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14)
+            BHW_CASE(15) BHW_CASE(16) BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20)
+            BHW_CASE_T(21) BHW_CASE_T(22) BHW_CASE_T(23) BHW_CASE_T(24) BHW_CASE_T(25) BHW_CASE_T(26) BHW_CASE_T(27) BHW_CASE_T(28)
+            BHW_CASE_T(29) BHW_CASE_T(30) BHW_CASE_T(31) BHW_CASE_T(32)
+        default: return (int)hipErrorInvalidValue;
+        }
+#undef BHW_CASE
+#undef BHW_CASE_T
+#undef BHW_LAUNCH_BUILD
+        return finish(hipSuccess);
+    }
+    if (c.tab_dlog > kPackLog) return (int)hipErrorInvalidValue;        // residual records come from the shared-prefix kernel only
+    if (c.wide) BHW_LAUNCH(k_table_build<int64_t>, dim3(grid_for(entries)), dim3(kBlock), 0, st, c, entries, (void *)d_table);
+    else        BHW_LAUNCH(k_table_build<int32_t>, dim3(grid_for(entries)), dim3(kBlock), 0, st, c, entries, (void *)d_table);
+    return finish(hipSuccess);
+}
+

@@ -1,0 +1,473 @@
+// bhw_fused.hip -- fused strategy: whole-period work in one launch, no table
+//
+// Part of the hand-written HIP kernels for gfx950 (MI355X, CDNA4) behind include/bhw.h.  Hot path of the reference: phase
+// accumulator -> CORDIC rotation chain (or Taylor LUT) -> weighted N-term cosine sum -> int32 coefficient (SURVEY section 8a
+// rows a1-a11).  Integer semantics follow SURVEY App. A; reference lines are cited at each step.
+#include "bhw_device.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// Fused fold kernel: whole-period work in ONE launch, no table.
+//
+// Lane r of the ring [0, N/8) owns the eight coefficients n = r + h*N/8 + j*N/4 (the quadrant + half-period fold of the tile
+// kernel) and runs the first-quadrant CORDIC chains they need itself: two per odd harmonic (entries K*r and K*r + E/2), one
+// per even harmonic -- 9 chains for 8 coefficients of a 7-term window instead of 48 in the direct kernel.  The 64 lanes of a
+// wave are consecutive r, so for every chain their leaves are equally spaced in angle and share a rotation prefix exactly as
+// the 64-leaf groups of k_table_build_shared do: phase 1 runs the (waves x chains) shared prefixes, one lane each, and parks
+// them in LDS; phase 2 is one lane per r.  The rotation count is a run-time loop bound, so one instance serves every width.
+//
+// Used for (a) short whole windows (2^9 .. ~2^20 coefficients), where the table strategy is two dependent launches around a
+// table round trip, and (b) interleaved ownership parts of a long window (bhw_generate_part_device): a device that owns 1/G of
+// the ring needs 9/8G chains per coefficient of the whole window, below the table's 1/4 once G >= 5.
+// The lanes of a launch are a list of runs of consecutive r (one run for a whole window; the 15 sibling runs of the tile plan,
+// split where they wrap, for an ownership part).
+// ---------------------------------------------------------------------------------------
+constexpr int kFoldRunsMax = 32;
+constexpr int kFoldBlock = 256;
+
+struct BhwFoldPlan {
+    uint32_t lut[34];                        // rescaled ROM as 32-bit words (quarter circle <= 2^32); [32], [33] = 0: the loop reads one ahead
+    int64_t  x0;
+    uint32_t n_iter, z_shr, z_shl, out_shr;
+    uint32_t n_runs, phi_width, dat_width, ones_neg;
+    uint32_t fast_mul, pad0;                 // 1: every harmonic weight below 2^(W-3): one-instruction products (tile_harmonic FAST)
+    uint32_t r0[kFoldRunsMax];               // first ring index of each run
+    uint32_t r_end[kFoldRunsMax];            // one past its last
+    uint32_t wg_first[kFoldRunsMax + 1];     // first workgroup of each run; [n_runs] = grid size
+};
+
+__host__ __device__ constexpr int fold_chains(int n_terms)      // first-quadrant chains per ring lane
+{
+    return n_terms == 2 ? 2 : n_terms == 3 ? 3 : n_terms == 4 ? 5 : n_terms == 5 ? 6 : 9;
+}
+
+
+// lutv: the rescaled ROM spread over the lanes of the wave (lane k holds lut[k]); v_readlane_b32 with the scalar rotation
+// counter fetches a word in a few cycles.  (As a scalar load from the kernel arguments every rotation waited ~100+ cycles for
+// its ROM word: short windows have too few waves to hide that, 9 us for a 2^16-point window.)
+__device__ __forceinline__ void chain_from(int64_t &x, int64_t &y, int32_t &z, int k0, int n_iter, uint32_t lutv)
+{
+    int k = k0;                                                   // 1 <= k0 <= 20, n_iter <= 32
+#pragma unroll 1
+    for (; k < n_iter && k < kMad24From; ++k)                     // the first rotations: ROM words of 24 bits and more
+        rot_step_dyn(x, y, z, k, (uint32_t)__builtin_amdgcn_readlane((int)lutv, k), false);
+#pragma unroll 1
+    for (; k < n_iter; ++k)
+        rot_step_dyn(x, y, z, k, (uint32_t)__builtin_amdgcn_readlane((int)lutv, k), true);
+}
+
+// LOCKSTEP selects how phase 2 walks a lane's chains:
+//   false: one chain after the other, each from its own split rotation (fewest rotations: the form for launches that fill the
+//          chip, which are bound by vector issue);
+//   true : all chains of the lane in one loop from the earliest split rotation of the wave -- a few rotations are repeated, but
+//          the NCH independent rotations per iteration hide the ~15-cycle dependent-issue latency that a single chain exposes
+//          when a launch has only a wave or two per SIMD (a 2^16-point window: 13 -> 6 us).
+// Phase 1 parks the shared state after every prefix rotation (20 levels x tasks x 20 bytes of LDS), so either form picks its
+// start level.
+constexpr int kFoldLevels = (kPrefixMax < 32 ? kPrefixMax : 32) + 1;
+
+template <int NTERMS, int MODE, bool LOCKSTEP>
+__global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win, BhwFoldPlan plan, int32_t *__restrict__ out)
+{
+    using acc_t = typename std::conditional<MODE == 2, Sum32, int32_t>::type;
+    constexpr int NCH = fold_chains(NTERMS);
+    constexpr int kTasks = (kFoldBlock / 64) * NCH;
+    __shared__ int64_t gx[kFoldLevels][kTasks], gy[kFoldLevels][kTasks];   // [level = rotations applied][wave * NCH + chain]
+    __shared__ uint32_t gdz[kFoldLevels][kTasks];
+    __shared__ int32_t gk[kTasks];
+    BhwCordicCfg cfg;                                                     // tile_harmonic() reads ones_neg only
+    cfg.ones_neg = plan.ones_neg;
+
+    const uint32_t lq = plan.phi_width - 2;
+    const uint32_t E = 1u << lq, emask = E - 1u, H = E >> 1;
+    const uint32_t W = plan.dat_width;
+    const int n_iter = (int)plan.n_iter;
+    uint32_t run = 0;                                                     // scalar search: at most kFoldRunsMax runs
+    while (run + 1u < plan.n_runs && blockIdx.x >= plan.wg_first[run + 1u]) ++run;
+    const uint32_t wg_r0 = plan.r0[run] + (blockIdx.x - plan.wg_first[run]) * blockDim.x;
+    const uint32_t r_end = plan.r_end[run];
+    const uint32_t n_waves = blockDim.x >> 6;
+    const uint32_t z_shr = plan.z_shr, z_shl = plan.z_shl, out_shr = plan.out_shr;
+
+    // ---- phase 1: shared rotation prefix of every (wave, chain) ----
+    // chain slot c -> harmonic K and half-period image: (1,0) (1,1) (2) (3,0) (3,1) (4) (5,0) (5,1) (6)
+    if (threadIdx.x < n_waves * NCH) {
+        const uint32_t wv = threadIdx.x / NCH, c = threadIdx.x % NCH;
+        const uint32_t K = 2u * (c / 3u) + 1u + (c % 3u == 2u ? 1u : 0u);
+        const uint32_t hodd = (c % 3u == 1u) ? 1u : 0u;
+        const uint32_t rf = wg_r0 + (wv << 6);
+        const uint32_t t0 = (K * rf + hodd * H) & emask;
+        const uint32_t tl = t0 + 63u * K;                                 // last leaf, if the 64 leaves do not wrap past E
+        const uint32_t z0f = (t0 >> z_shr) << z_shl;
+        bool live = tl <= emask;                                          // wrapped groups are not contiguous in angle: no sharing
+        const uint32_t span = live ? ((tl >> z_shr) << z_shl) - z0f : 0u;
+        int64_t x = plan.x0, y = plan.x0;                                 // after rotation 0 (z0 >= 0 always adds)
+        int32_t zf = (int32_t)(z0f - plan.lut[0]);
+        int k = 1;
+        gx[1][threadIdx.x] = x;
+        gy[1][threadIdx.x] = y;
+        gdz[1][threadIdx.x] = (uint32_t)zf - z0f;                         // z_level(leaf) = z0(leaf) + this, for every leaf of the group
+#pragma unroll
+        for (int kk = 1; kk < kFoldLevels - 1; ++kk) {
+            if (live && kk < n_iter) {
+                const int32_t zl = (int32_t)((uint32_t)zf + span);
+                if ((zf < 0) != (zl < 0)) {
+                    live = false;                                         // the group splits at rotation kk
+                } else {
+                    rot_step(x, y, zf, kk, plan.lut[kk]);
+                    k = kk + 1;
+                    gx[kk + 1][threadIdx.x] = x;
+                    gy[kk + 1][threadIdx.x] = y;
+                    gdz[kk + 1][threadIdx.x] = (uint32_t)zf - z0f;
+                }
+            }
+        }
+        gk[threadIdx.x] = k;
+    }
+    __syncthreads();
+
+    // ---- phase 2: one lane per r ----
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t r = wg_r0 + threadIdx.x;
+    const uint32_t lutv = plan.lut[threadIdx.x & 31u];                    // lane k (and k + 32) holds lut[k]
+    const bool fast = MODE != 2 && plan.fast_mul != 0u;
+    acc_t acc[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (MODE == 2) acc[h][j] = Sum32{win.aa[0] >> 2, win.aa[0] & 3};
+            else acc[h][j] = win.aa[0];
+        }
+    // slot -> (K, half-period image) as compile-time functions of the slot
+    auto slot_K = [](int slot) { return 2 * (slot / 3) + 1 + (slot % 3 == 2 ? 1 : 0); };
+    auto slot_h = [](int slot) { return slot % 3 == 1 ? 1u : 0u; };
+    int2 cs[NCH];
+    if constexpr (LOCKSTEP) {
+        int kc = 32;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int kq = __builtin_amdgcn_readfirstlane(gk[wave * NCH + c]);
+            kc = kq < kc ? kq : kc;
+        }
+        int64_t x[NCH], y[NCH];
+        int32_t z[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const uint32_t i = wave * NCH + c;
+            x[c] = gx[kc][i];
+            y[c] = gy[kc][i];
+            const uint32_t t = ((uint32_t)slot_K(c) * r + slot_h(c) * H) & emask;
+            z[c] = (int32_t)(((t >> z_shr) << z_shl) + gdz[kc][i]);
+        }
+        int k = kc;
+#pragma unroll 1
+        for (; k < n_iter && k < kMad24From; ++k) {
+            const uint32_t lutk = (uint32_t)__builtin_amdgcn_readlane((int)lutv, k);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) rot_step_dyn(x[c], y[c], z[c], k, lutk, false);
+        }
+#pragma unroll 1
+        for (; k < n_iter; ++k) {
+            const uint32_t lutk = (uint32_t)__builtin_amdgcn_readlane((int)lutv, k);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) rot_step_dyn(x[c], y[c], z[c], k, lutk, true);
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) cs[c] = make_int2((int32_t)(x[c] >> out_shr), (int32_t)(y[c] >> out_shr));
+    }
+    auto chain = [&](const uint32_t slot, const uint32_t K, const uint32_t hodd) -> int2 {
+        if constexpr (LOCKSTEP) return cs[slot];
+        const uint32_t i = wave * NCH + slot;                             // scalar: the parked state is read as a broadcast
+        const int k0 = __builtin_amdgcn_readfirstlane(gk[i]);
+        int64_t x = gx[k0][i], y = gy[k0][i];
+        const uint32_t t = (K * r + hodd * H) & emask;
+        int32_t z = (int32_t)(((t >> z_shr) << z_shl) + gdz[k0][i]);
+        chain_from(x, y, z, k0, n_iter, lutv);
+        return make_int2((int32_t)(x >> out_shr), (int32_t)(y >> out_shr));
+    };
+#define BHW_FD_TERM(K, HH, CS, ACC, OFF)                                                                 \
+    if (fast) {                                                           /* scalar branch */        \
+        tile_harmonic<K, MODE, ring_qbase(K, HH), ring_qbits(K, HH), MODE != 2>(cfg, (int32_t)((uint32_t)win.aa[K] << (34u - W)), W, CS, \
+                                                                                ((uint32_t)K * (r + (uint32_t)HH * H)) >> lq, sv); \
+        tile_accumulate<K, OFF, MODE != 2>(sv, ACC);                                                 \
+    } else {                                                                                         \
+        tile_harmonic<K, MODE, ring_qbase(K, HH), ring_qbits(K, HH)>(cfg, win.aa[K], W, CS, ((uint32_t)K * (r + (uint32_t)HH * H)) >> lq, sv); \
+        tile_accumulate<K, OFF>(sv, ACC);                                                            \
+    }
+#define BHW_FD_HARMONIC(K)                                                                           \
+    if constexpr (NTERMS > K) {                                                                      \
+        constexpr uint32_t slot = ((K - 1) / 2) * 3 + ((K & 1) ? 0 : 2);                             \
+        int32_t sv[4];                                                                               \
+        const int2 cs0 = chain(slot, K, 0u);                                                         \
+        if constexpr ((K & 1) != 0) {                                                                \
+            BHW_FD_TERM(K, 0, cs0, acc[0], 0)                                                        \
+            const int2 cs1 = chain(slot + 1u, K, 1u);                                                \
+            BHW_FD_TERM(K, 1, cs1, acc[1], 0)                                                        \
+        } else {                                                                                     \
+            if (fast) {                                                                              \
+                tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0), MODE != 2>(cfg, (int32_t)((uint32_t)win.aa[K] << (34u - W)), W, cs0, ((uint32_t)K * r) >> lq, sv); \
+                tile_accumulate<K, 0, MODE != 2>(sv, acc[0]);                                        \
+                tile_accumulate<K, K / 2, MODE != 2>(sv, acc[1]);                                    \
+            } else {                                                                                 \
+                tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0)>(cfg, win.aa[K], W, cs0, ((uint32_t)K * r) >> lq, sv); \
+                tile_accumulate<K, 0>(sv, acc[0]);                                                   \
+                tile_accumulate<K, K / 2>(sv, acc[1]);                                               \
+            }                                                                                        \
+        }                                                                                            \
+    }
+    BHW_FD_HARMONIC(1) BHW_FD_HARMONIC(2) BHW_FD_HARMONIC(3) BHW_FD_HARMONIC(4) BHW_FD_HARMONIC(5) BHW_FD_HARMONIC(6)
+#undef BHW_FD_TERM
+#undef BHW_FD_HARMONIC
+    if (r >= r_end) return;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int32_t v;
+            if constexpr (MODE == 2) v = w32_final<BHW_COMBINE_VHDL>(acc[h][j], W, NTERMS);
+            else v = (int32_t)((uint32_t)acc[h][j] << (32u - W)) >> (32u - W);         // (win_t)(...) wrap to W bits
+            emit(win, out, (uint64_t)(r + (uint32_t)h * H) + (uint64_t)j * E, v);
+        }
+}
+
+// Fused fold kernel, short-launch form: the chains of 64 ring lanes SPLIT OVER THE FOUR WAVES of a workgroup (one per SIMD).
+// A launch of a few thousand lanes is bound by the serial depth of one wave -- prefix, then 5 .. 9 chains -- not by issue
+// slots; here wave w takes chains w, w + 4, w + 8 of the same 64 lanes (at most three), runs their prefixes in its first lanes,
+// broadcasts them with v_readlane (no LDS, no barrier), walks them together from the earliest split level (each chain joining
+// at its own), and hands the (c, s) pairs over through LDS; waves 0 and 1 then sum the h = 0 / h = 1 images.
+// The z recurrence takes the short path z += sg * (-lut) (sign, or, mad: three dependent instructions instead of four).
+template <bool MAD24>
+__device__ __forceinline__ void rot_step_lat(int64_t &x, int64_t &y, int32_t &z, int k, int32_t nlutk)
+{
+    const int32_t sg = (z >> 31) | 1;
+    int32_t ys = (int32_t)__builtin_amdgcn_alignbit((uint32_t)((uint64_t)y >> 32), (uint32_t)y, (uint32_t)k);
+    int32_t xs = (int32_t)__builtin_amdgcn_alignbit((uint32_t)((uint64_t)x >> 32), (uint32_t)x, (uint32_t)k);
+    asm volatile("" : "+v"(ys), "+v"(xs));
+    if constexpr (MAD24) z += __mul24(sg, nlutk);                // |lut[k]| < 2^23 from rotation kMad24From on
+    else z += sg * nlutk;                                        // 32-bit product: exact modulo 2^32 for every ROM word
+    x -= (int64_t)sg * (int64_t)ys;
+    y += (int64_t)sg * (int64_t)xs;
+}
+
+template <int NTERMS, int MODE>
+__global__ __launch_bounds__(256) void k_fold_split(BhwWinCfg win, BhwFoldPlan plan, int32_t *__restrict__ out)
+{
+    using acc_t = typename std::conditional<MODE == 2, Sum32, int32_t>::type;
+    constexpr int NCH = fold_chains(NTERMS);
+    constexpr int MAXC = (NCH + 3) / 4;                                   // chains per wave
+    __shared__ int2 cs_s[NCH][64];
+    BhwCordicCfg cfg;                                                     // tile_harmonic() reads ones_neg only
+    cfg.ones_neg = plan.ones_neg;
+    const uint32_t lq = plan.phi_width - 2;
+    const uint32_t E = 1u << lq, emask = E - 1u, H = E >> 1;
+    const uint32_t W = plan.dat_width;
+    const int n_iter = (int)plan.n_iter;
+    uint32_t run = 0;
+    while (run + 1u < plan.n_runs && blockIdx.x >= plan.wg_first[run + 1u]) ++run;
+    const uint32_t wg_r0 = plan.r0[run] + (blockIdx.x - plan.wg_first[run]) * 64u;      // 64 ring lanes per workgroup
+    const uint32_t r_end = plan.r_end[run];
+    const uint32_t z_shr = plan.z_shr, z_shl = plan.z_shl, out_shr = plan.out_shr;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t r = wg_r0 + lane;
+    const int32_t nlutv = -(int32_t)plan.lut[lane & 31u];                 // lane k holds -lut[k]
+
+    auto chain_K = [](uint32_t c) { return 2u * (c / 3u) + 1u + (c % 3u == 2u ? 1u : 0u); };
+    auto chain_h = [](uint32_t c) { return (c % 3u == 1u) ? 1u : 0u; };
+
+    // ---- phase 1: lane i < MAXC runs the shared prefix of this wave's chain i (chain index wave + 4 i) ----
+    int64_t px = plan.x0, py = plan.x0;
+    uint32_t pdz = 0u;
+    int pk = 1;
+    {
+        const uint32_t ci = lane < (uint32_t)MAXC ? lane : 0u;
+        uint32_t c = wave + 4u * ci;
+        if (c >= (uint32_t)NCH) c = wave < (uint32_t)NCH ? wave : 0u;     // idle lanes / waves repeat a valid chain
+        const uint32_t K = chain_K(c), hodd = chain_h(c);
+        const uint32_t t0 = (K * wg_r0 + hodd * H) & emask;
+        const uint32_t tl = t0 + 63u * K;
+        const uint32_t z0f = (t0 >> z_shr) << z_shl;
+        bool live = tl <= emask;
+        const uint32_t span = live ? ((tl >> z_shr) << z_shl) - z0f : 0u;
+        int32_t zf = (int32_t)(z0f - plan.lut[0]);
+        constexpr int kmax = kPrefixMax < 32 ? kPrefixMax : 32;
+#pragma unroll
+        for (int kk = 1; kk < kmax; ++kk) {
+            if (live && kk < n_iter) {
+                const int32_t zl = (int32_t)((uint32_t)zf + span);
+                if ((zf < 0) != (zl < 0)) {
+                    live = false;
+                } else {
+                    rot_step(px, py, zf, kk, plan.lut[kk]);
+                    pk = kk + 1;
+                }
+            }
+        }
+        pdz = (uint32_t)zf - z0f;
+    }
+    // ---- phase 2: this wave's chains, every lane its own leaf ----
+    int64_t x[MAXC], y[MAXC];
+    int32_t z[MAXC];
+    int k0[MAXC];
+    int kc = 32;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const uint32_t c = wave + 4u * (uint32_t)i;
+        const uint32_t cc = c < (uint32_t)NCH ? c : 0u;
+        const uint32_t xl = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)px, i), xh = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)px >> 32), i);
+        const uint32_t yl = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)py, i), yh = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)py >> 32), i);
+        x[i] = (int64_t)(((uint64_t)xh << 32) | xl);
+        y[i] = (int64_t)(((uint64_t)yh << 32) | yl);
+        const uint32_t dz = (uint32_t)__builtin_amdgcn_readlane((int)pdz, i);
+        k0[i] = c < (uint32_t)NCH ? __builtin_amdgcn_readlane(pk, i) : 32;     // chains this wave does not have never start
+        const uint32_t t = (chain_K(cc) * r + chain_h(cc) * H) & emask;
+        z[i] = (int32_t)(((t >> z_shr) << z_shl) + dz);
+        kc = k0[i] < kc ? k0[i] : kc;
+    }
+    int k = kc;
+#pragma unroll 1
+    for (; k < n_iter && k < kMad24From; ++k) {
+        const int32_t nlutk = __builtin_amdgcn_readlane(nlutv, k);
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i)
+            if (k >= k0[i]) rot_step_lat<false>(x[i], y[i], z[i], k, nlutk);   // scalar guard: k0 is wave-uniform
+    }
+#pragma unroll 1
+    for (; k < n_iter; ++k) {
+        const int32_t nlutk = __builtin_amdgcn_readlane(nlutv, k);
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i)
+            if (k >= k0[i]) rot_step_lat<true>(x[i], y[i], z[i], k, nlutk);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const uint32_t c = wave + 4u * (uint32_t)i;
+        if (c < (uint32_t)NCH) cs_s[c][lane] = make_int2((int32_t)(x[i] >> out_shr), (int32_t)(y[i] >> out_shr));
+    }
+    __syncthreads();
+    if (wave >= 2u || r >= r_end) return;
+
+    // ---- combine: wave h sums the four images n = r + h*N/8 + j*N/4 ----
+    auto combine = [&](auto hc) {
+        constexpr int HH = decltype(hc)::value;
+        acc_t acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (MODE == 2) acc[j] = Sum32{win.aa[0] >> 2, win.aa[0] & 3};
+            else acc[j] = win.aa[0];
+        }
+#define BHW_FS_HARMONIC(K)                                                                                            \
+        if constexpr (NTERMS > K) {                                                                                   \
+            constexpr uint32_t slot = ((K - 1) / 2) * 3 + ((K & 1) ? (uint32_t)HH : 2u);                              \
+            int32_t sv[4];                                                                                            \
+            if constexpr ((K & 1) != 0) {                                                                             \
+                tile_harmonic<K, MODE, ring_qbase(K, HH), ring_qbits(K, HH)>(cfg, win.aa[K], W, cs_s[slot][lane],     \
+                                                                            ((uint32_t)K * (r + (uint32_t)HH * H)) >> lq, sv); \
+                tile_accumulate<K, 0>(sv, acc);                                                                       \
+            } else {                                                                                                  \
+                tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0)>(cfg, win.aa[K], W, cs_s[slot][lane], ((uint32_t)K * r) >> lq, sv); \
+                tile_accumulate<K, (HH ? K / 2 : 0)>(sv, acc);                                                        \
+            }                                                                                                         \
+        }
+        BHW_FS_HARMONIC(1) BHW_FS_HARMONIC(2) BHW_FS_HARMONIC(3) BHW_FS_HARMONIC(4) BHW_FS_HARMONIC(5) BHW_FS_HARMONIC(6)
+#undef BHW_FS_HARMONIC
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int32_t v;
+            if constexpr (MODE == 2) v = w32_final<BHW_COMBINE_VHDL>(acc[j], W, NTERMS);
+            else v = (int32_t)((uint32_t)acc[j] << (32u - W)) >> (32u - W);
+            emit(win, out, (uint64_t)(r + (uint32_t)HH * H) + (uint64_t)j * E, v);
+        }
+    };
+    if (wave == 0u) combine(std::integral_constant<int, 0>{});
+    else combine(std::integral_constant<int, 1>{});
+}
+
+} // namespace
+
+bool bhwk_fold_direct_applicable(const BhwCordicCfg &c)
+{
+    // rot_step's forms: |x| < 2^33 and a quarter circle <= 2^32; ring of at least one wave
+    return c.dat_width + c.out_shr <= 34 && c.phi_width >= 9 && c.phi_width <= 30 && c.n_iter >= 2;
+}
+
+int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const BhwFoldRun *runs, uint32_t n_runs, int32_t *d_out)
+{
+    if (!n_runs) return 0;
+    if (n_runs > (uint32_t)kFoldRunsMax || !bhwk_fold_direct_applicable(c)) return (int)hipErrorInvalidValue;
+    BHW_SET_DEVICE(l);
+    hipStream_t st = (hipStream_t)l.stream;
+    BhwFoldPlan plan;
+    memset(&plan, 0, sizeof plan);
+    for (uint32_t k = 0; k < 32; ++k) plan.lut[k] = (uint32_t)c.lut[k];
+    plan.x0 = c.x0;
+    plan.n_iter = c.n_iter;
+    plan.z_shr = c.z_shr;
+    plan.z_shl = c.z_shl;
+    plan.out_shr = c.out_shr;
+    plan.n_runs = n_runs;
+    plan.phi_width = c.phi_width;
+    plan.dat_width = c.dat_width;
+    plan.ones_neg = c.ones_neg;
+    plan.fast_mul = (w.combine == BHW_COMBINE_HLS && c.dat_width >= 3) ? 1u : 0u;
+    for (uint32_t k = 1; k < w.n_terms && plan.fast_mul; ++k) {
+        const int64_t lim = (int64_t)1 << (c.dat_width - 3);
+        if ((int64_t)w.aa[k] >= lim || (int64_t)w.aa[k] <= -lim) plan.fast_mul = 0u;
+    }
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_runs; ++i) total += runs[i].r_end - runs[i].r0;
+    // short launches: one wave per workgroup spreads the few waves over more CUs
+    const uint32_t block = total <= 64u * 1024u ? 64u : (uint32_t)kFoldBlock;
+    uint32_t wg = 0;
+    for (uint32_t i = 0; i < n_runs; ++i) {
+        plan.r0[i] = runs[i].r0;
+        plan.r_end[i] = runs[i].r_end;
+        plan.wg_first[i] = wg;
+        wg += (runs[i].r_end - runs[i].r0 + block - 1u) / block;
+    }
+    plan.wg_first[n_runs] = wg;
+    if (!wg) return 0;
+    const int mode = (w.combine != BHW_COMBINE_HLS) ? 2 : (c.ones_neg ? 1 : 0);
+    const dim3 grid(wg), blk(block);
+    // fewer than ~4 waves per SIMD in the whole launch: latency-bound, walk the chains in lockstep
+    const bool lockstep = total <= (1u << 18);
+    // short launches, form of the kernel: 2 = chains split over four waves per 64 lanes (k_fold_split), 1 = lockstep, 0 = sequential
+    // measured per call (profiles/r02_ab_fused_lockstep.txt): split 7.8 / lockstep 9.0 us at 2^13 lanes (BH-7 2^16), 6.9 / 7.7 at
+    // 2^15 (BH-5 2^18), 9.7 / 9.7 at 2^16, 9.0 / 8.2 at 2^17 (BH-4 2^20): split up to 2^15 lanes, lockstep up to 2^18
+    const bool split = total <= (1u << 15);
+    dim3 grid_s(0), blk_s(256);
+    if (split) {
+        uint32_t wgs = 0;
+        for (uint32_t i = 0; i < n_runs; ++i) {
+            plan.wg_first[i] = wgs;
+            wgs += (runs[i].r_end - runs[i].r0 + 63u) / 64u;
+        }
+        plan.wg_first[n_runs] = wgs;
+        grid_s = dim3(wgs);
+    }
+#define BHW_FD_NT_M(NT, M)                                                                                  \
+    do {                                                                                                    \
+        if (split) BHW_LAUNCH((k_fold_split<NT, M>), grid_s, blk_s, 0, st, w, plan, d_out);               \
+        else if (lockstep) BHW_LAUNCH((k_fold_direct<NT, M, true>), grid, blk, 0, st, w, plan, d_out); \
+        else          BHW_LAUNCH((k_fold_direct<NT, M, false>), grid, blk, 0, st, w, plan, d_out);          \
+    } while (0)
+#define BHW_FD_NT(NT)                                                                                       \
+    do {                                                                                                    \
+        if (mode == 0)      BHW_FD_NT_M(NT, 0);                                                             \
+        else if (mode == 1) BHW_FD_NT_M(NT, 1);                                                             \
+        else                BHW_FD_NT_M(NT, 2);                                                             \
+    } while (0)
+    switch (w.n_terms) {
+    case 2: BHW_FD_NT(2); break;
+    case 3: BHW_FD_NT(3); break;
+    case 4: BHW_FD_NT(4); break;
+    case 5: BHW_FD_NT(5); break;
+    case 7: BHW_FD_NT(7); break;
+    default: return (int)hipErrorInvalidValue;
+    }
+#undef BHW_FD_NT
+#undef BHW_FD_NT_M
+    return finish(hipSuccess);
+}
+

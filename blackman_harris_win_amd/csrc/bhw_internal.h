@@ -22,7 +22,7 @@ struct BhwCordicCfg {
     uint32_t ones_neg;    // 1: quadrant map negates with ~v (CPP); 0: -v
     uint32_t wide;        // 1: state needs more than 32 bits
     uint32_t tab_split;   // table layout: 0 natural index u; 1 split by residue class (u%4==0 | u%4==2 | u odd)
-    uint32_t tab_dlog;    // table format (tab_load() in bhw_kernels.hip): 0 plain int2 (c, s) entries; 6 "delta16" -- one dword of
+    uint32_t tab_dlog;    // table format (tab_load() in bhw_device.h): 0 plain int2 (c, s) entries; 6 "delta16" -- one dword of
                           // two int16 differences to the first entry of the 64-entry block, block heads as int2 records at
                           // tab_coarse; 7..9 "residual" -- two bytes per entry against a linear predictor, int4 {c, s, dc, ds}
                           // records every 2^tab_dlog entries at tab_coarse
@@ -67,7 +67,7 @@ struct BhwLaunch {
     void *stream;
 };
 
-// kernels (bhw_kernels.hip) -- each returns a hipError_t cast to int
+// kernel launchers (bhw_direct / bhw_build / bhw_combine / bhw_fused / bhw_taylor / bhw_variants .hip) -- each returns a hipError_t cast to int
 int bhwk_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w,
                 uint64_t n0, uint64_t count, int32_t *d_out);
 int bhwk_sincos(const BhwLaunch &l, const BhwCordicCfg &c, uint64_t theta0, uint64_t count,
@@ -79,6 +79,10 @@ int bhwk_replicate(const BhwLaunch &l, const int32_t *d_frame, uint64_t frame_le
 int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c, int32_t *d_table /* (c,s) pairs, 2^(PW-2) */);
 int bhwk_table_combine(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table,
                        uint64_t n0, uint64_t count, int32_t *d_out);
+// whole-period cordic() sweep through the shared-prefix chains of the table build (bhwk_sincos picks it for periods >= 2^16)
+int bhwk_sincos_sweep(const BhwLaunch &l, const BhwCordicCfg &c, uint64_t theta0, int32_t *d_sin, int32_t *d_cos);
+// the octant-mirror build kernel applies to this table (bhw_build.hip; bhwk_describe_table names the kernel)
+bool bhwk_build_mirror_applies(const BhwCordicCfg &c, uint32_t entries);
 // which packed table formats a configuration admits (delta16; residual cell size, 0 = not applicable)
 bool bhwk_packed_ok(const BhwCordicCfg &c);
 uint32_t bhwk_resid_dlog(const BhwCordicCfg &c);

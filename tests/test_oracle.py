@@ -315,7 +315,7 @@ def test_typed_store_wraps_never_fire():
 
 
 def test_residual_format_margin():
-    """The 2-byte "residual" table format (bhw_kernels.hip) stores (c, s) minus a straight line through exact records 2^d
+    """The 2-byte "residual" table format (csrc/bhw_device.h) stores (c, s) minus a straight line through exact records 2^d
     entries apart in one signed byte per component.  Measure that deviation over every model, at the widths the format is used
     for (d from the same rule as bhwk_resid_dlog): it must stay far inside int8."""
     rng = np.random.default_rng(17)

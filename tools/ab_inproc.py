@@ -18,21 +18,13 @@ def build_variant(idx, flags):
     # variants are cached under build/ab/ by (flags, source hash): prebuild them in the CPU container with --build-only,
     # the snapshot carries them to the GPU box (GPU minutes are not spent compiling)
     import hashlib
-    srcs = [os.path.join(_build.CSRC, f) for f in ("bhw_api.cpp", "bhw_kernels.hip", "bhw_rom.c", "bhw_internal.h", "bhw_tables.inc")]
-    tag = hashlib.sha256((flags + _build._digest(srcs)).encode()).hexdigest()[:16]
+    tag = hashlib.sha256((flags + _build._digest(_build.library_sources())).encode()).hexdigest()[:16]
     out = os.path.join(ROOT, "build", "ab", f"libbhw_{tag}.so")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     if os.path.exists(out):
         return out
-    csrc = _build.CSRC
-    rom_o = os.path.join(csrc, "bhw_rom.o")
-    if not os.path.exists(rom_o):
-        subprocess.check_call(["gcc", "-O2", "-fPIC", "-c", os.path.join(csrc, "bhw_rom.c"), "-o", rom_o])
-    quad = subprocess.run(["gcc", "-print-file-name=libquadmath.so"], stdout=subprocess.PIPE, text=True).stdout.strip()
-    cmd = [_build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function"] + \
-        flags.split() + ["-x", "hip", os.path.join(csrc, "bhw_api.cpp"), os.path.join(csrc, "bhw_kernels.hip"),
-                         "-x", "none", rom_o, quad, "-Wl,-rpath," + os.path.dirname(os.path.realpath(quad)), "-o", out]
-    subprocess.check_call(cmd)
+    objects, _ = _build.compile_units(os.path.join(ROOT, "build", "ab", "obj_" + tag), flags.split())
+    _build.link_library(objects, out)
     return out
 
 

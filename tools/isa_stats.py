@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Resource usage and instruction mix of the kernels in an ISA listing of csrc/bhw_kernels.hip.
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S blackman_harris_win_amd/csrc/bhw_kernels.hip -o /tmp/k.s
+"""Resource usage and instruction mix of the kernels in an ISA listing of one kernel translation unit (csrc/bhw_*.hip).
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S blackman_harris_win_amd/csrc/bhw_build.hip -o /tmp/k.s
     python tools/isa_stats.py /tmp/k.s 'k_table_combine_tile<15, 0, 2>' [--mix]
 """
 import collections
