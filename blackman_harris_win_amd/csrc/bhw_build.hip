@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
     }
 }
 
-// Table strategy, pass 1, octant-mirror form (residual / nibble formats in the split layout).
+// Table strategy, pass 1, octant-mirror form (residual / nibble formats).
 //
 // After rotation 0 the state is the 45-degree vector (x0, x0) and 2 * lut[0] is exactly a quarter turn (checked by the launcher),
 // so the chain of u' = E - u is the chain of u with x and y swapped, z negated and every decision flipped -- bit for bit, floors
@@ -209,26 +209,105 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
 // rotations (|z| is a few units there), so:
 //   * only u in [0, E/2) run a chain of their own; u' in (E/2, E) are images of u in [1, E/2 - 1]; the middle entry E/2 is a
 //     deferred chain of the last workgroup;
-//   * at rotation KS = NITER - kMirrorTail the image state is taken as (y, x, -z) and the last rotations run for both;
+//   * at rotation KS = NITER - kMirrorTail the image state is taken as (y, x, -z) and the last rotations are evaluated for both;
 //   * a lane that met z_k == 0 before KS (one v_cmp per shared rotation, collected in a scalar mask; about 1 % of the lanes, but
 //     every second wave has one) does not store its image: it appends u to a worklist in shared memory, and after the groups
 //     the workgroup's first lanes run those images as chains of their own (a wave-wide replay in place costs more than the
 //     symmetry saves);
 //   * a group whose shared prefix itself met z == 0 (only its leaf 0 can) recomputes that one image from scratch;
 //   * the records of the image cells come from chains of their own (third wave), never from the symmetry.
-// Per pair of entries 9 shared + 2 x 6 own rotations instead of 2 x 15.
-constexpr int kMirrorTail = 6;         // rotations run separately for an entry and its image (tails of 5 or 7 measured slower)
+//
+// Round 3: two exact short cuts inside a group, both established on the host by tools/sim_build.cpp (every entry of the tables
+// of the BASELINE configurations against the plain chain) and covered on the device by the parity tests:
+//   NARROW STATE.  From its split rotation k0 on a group's leaves move x and y by less than D = 2^(NITER - k0 + 1) + 2 in total,
+//     so when the parked group state satisfies D <= X, Y and X + D, Y + D < 2^NITER (a scalar test in phase 1; 99 % of the
+//     groups: all but the first degree of the octant) every x_k, y_k of every leaf lies in [0, 2^NITER), NITER <= 32: the
+//     rotations run on 32-bit unsigned words with logical shifts, and the decision is applied by masking EXEC -- one compare,
+//     then add / sub / add on the lanes with z < 0 and sub / add / sub on the others: 9 plain VOP2 instructions (+ the zero test)
+//     instead of 2 x v_mad_i64_i32, 2 x v_alignbit_b32 and v_mad_i32_i24 among 9 (those issue in 4.2 - 4.8 cycles, plain
+//     VOP2 in 2.5: profiles/r02_ubench_gfx950.txt).  The other groups run the 64-bit rotation as a rolled loop.
+//   TABLE TAIL.  In such a group x_k >> k for k >= KS is (x_KS >> KS) >> (k - KS) as long as the low KS bits of x_KS keep a
+//     margin of 128 to both ends (the tail moves x by at most 120): the last kMirrorTail rotations collapse to
+//         x_end = x_KS - D[p][y_KS >> KS],   y_end = y_KS + D[p][x_KS >> KS],   D[p][v] = sum_j sigma_j(p) (v >> j),
+//     p = the tail's decision pattern, a function of z_KS alone (|z_KS| < 256 at every width: table tail_p, rebuilt from the
+//     ROM by every workgroup), D a 64 x 64 byte table (kTailD).  The image reads the same tables with z -> -z and x, y swapped.
+//     Two table reads per coordinate instead of six rotations; a wave with a lane outside the margins (50 of 131 072 waves at
+//     2^26 / 32 bits) runs the six rotations instead (wave-uniform branch).
+// Per pair of entries: 9 shared rotations of 10 instructions + ~25 for the two tails, instead of 9 + 2 x 6 rotations of 9.
+constexpr int kMirrorTail = 6;         // rotations of the table tail (D's row index has kMirrorTail bits, its column 32 - KS <= 6 bits)
 constexpr int kMirrorGpw = 64;         // own groups per workgroup
+constexpr int kTailZ = 256;            // tail_p covers z_KS in (-kTailZ, kTailZ)
+
+struct TailD { int8_t v[64 * 64]; };
+constexpr TailD make_tail_d()
+{
+    TailD t{};
+    for (int p = 0; p < 64; ++p)
+        for (int v = 0; v < 64; ++v) {
+            int d = 0;
+            for (int j = 0; j < kMirrorTail; ++j) d += ((p >> j) & 1) ? -(v >> j) : (v >> j);   // bit j set: z < 0 at rotation KS + j
+            t.v[p * 64 + v] = (int8_t)d;
+        }
+    return t;
+}
+__device__ const TailD kTailD = make_tail_d();
+
+// One rotation on the narrow state (see above); K is an immediate, lutk a scalar.  ZERO: also collect z == 0 into zm.
+template <int K, bool ZERO>
+__device__ __forceinline__ void rot_narrow(uint32_t &x, uint32_t &y, int32_t &z, uint64_t &zm, uint32_t lutk)
+{
+    uint32_t a, b;
+    uint64_t sv;
+    if constexpr (ZERO) {
+        asm volatile("v_lshrrev_b32 %[a], %[k], %[y]\n\t"
+                     "v_lshrrev_b32 %[b], %[k], %[x]\n\t"
+                     "v_cmp_eq_u32 vcc, 0, %[z]\n\t"
+                     "s_or_b64 %[zm], %[zm], vcc\n\t"
+                     "s_mov_b64 %[sv], exec\n\t"
+                     "v_cmpx_gt_i32 vcc, 0, %[z]\n\t"
+                     "v_add_u32 %[x], %[x], %[a]\n\t"
+                     "v_sub_u32 %[y], %[y], %[b]\n\t"
+                     "v_add_u32 %[z], %[z], %[l]\n\t"
+                     "s_andn2_b64 exec, %[sv], exec\n\t"
+                     "v_sub_u32 %[x], %[x], %[a]\n\t"
+                     "v_add_u32 %[y], %[y], %[b]\n\t"
+                     "v_sub_u32 %[z], %[z], %[l]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [zm] "+s"(zm), [a] "=&v"(a), [b] "=&v"(b), [sv] "=&s"(sv)
+                     : [l] "s"(lutk), [k] "n"(K)
+                     : "vcc");
+    } else {
+        asm volatile("v_lshrrev_b32 %[a], %[k], %[y]\n\t"
+                     "v_lshrrev_b32 %[b], %[k], %[x]\n\t"
+                     "s_mov_b64 %[sv], exec\n\t"
+                     "v_cmpx_gt_i32 vcc, 0, %[z]\n\t"
+                     "v_add_u32 %[x], %[x], %[a]\n\t"
+                     "v_sub_u32 %[y], %[y], %[b]\n\t"
+                     "v_add_u32 %[z], %[z], %[l]\n\t"
+                     "s_andn2_b64 exec, %[sv], exec\n\t"
+                     "v_sub_u32 %[x], %[x], %[a]\n\t"
+                     "v_add_u32 %[y], %[y], %[b]\n\t"
+                     "v_sub_u32 %[z], %[z], %[l]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [a] "=&v"(a), [b] "=&v"(b), [sv] "=&s"(sv)
+                     : [l] "s"(lutk), [k] "n"(K)
+                     : "vcc");
+    }
+}
+
 template <int NITER, int FMT>
 __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPlan plan, void *__restrict__ table)
 {
     static_assert(FMT == 2 || FMT == 3, "residual / nibble entries");
+    static_assert(NITER >= 21 && NITER <= 32, "narrow state: 32-bit words");
     __shared__ int64_t gx[kGroupsPerWg];
     __shared__ int64_t gy[kGroupsPerWg];
     __shared__ int32_t gz[kGroupsPerWg];
     __shared__ int32_t gk[kGroupsPerWg];
-    __shared__ uint32_t gflag[kGroupsPerWg];
+    __shared__ uint32_t gflag[kGroupsPerWg];                    // bit 0: leaf 0 met z == 0 inside the shared prefix; bit 1: narrow state
     __shared__ uint32_t lut_s[32];
+    __shared__ uint16_t tail_p[2 * kTailZ];                     // z_KS + kTailZ -> 64 * (decision pattern of the tail)
+    __shared__ __attribute__((aligned(16))) int8_t tail_d[64 * 64];
     constexpr uint32_t kWorkMax = 512;               // images to run as chains of their own (expected ~40 per workgroup)
     __shared__ uint32_t work_n;
     __shared__ uint32_t work_u[kWorkMax];
@@ -249,6 +328,19 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
             work_u[0] = E >> 1;
             work_n = 1u;
         }
+    }
+    // tail tables: D copied from its constant image (16 bytes per thread), the pattern of every z_KS from the ROM words
+    reinterpret_cast<int4 *>(tail_d)[threadIdx.x] = reinterpret_cast<const int4 *>(kTailD.v)[threadIdx.x];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const uint32_t zi = threadIdx.x + (uint32_t)half * kBuildThreads;
+        int32_t z = (int32_t)zi - kTailZ;
+        uint32_t p = 0u;
+#pragma unroll
+        for (int j = 0; j < kMirrorTail; ++j) {
+            if (z < 0) { p |= 1u << j; z += (int32_t)plan.lut[KS + j]; } else z -= (int32_t)plan.lut[KS + j];
+        }
+        tail_p[zi] = (uint16_t)(p << 6);
     }
     __syncthreads();
 
@@ -310,11 +402,14 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
                 }
             }
         }
+        // narrow state: every later x_k, y_k of every leaf stays inside [0, 2^NITER) (see the head comment)
+        const int64_t drift = ((int64_t)1 << (NITER - k + 1)) + 2, lim = (int64_t)1 << NITER;
+        const bool narrow = x >= drift && y >= drift && x + drift < lim && y + drift < lim;
         gx[threadIdx.x] = x;
         gy[threadIdx.x] = y;
         gz[threadIdx.x] = zf;
         gk[threadIdx.x] = k;
-        gflag[threadIdx.x] = zero0;
+        gflag[threadIdx.x] = zero0 | (narrow ? 2u : 0u);
     }
     __syncthreads();
 
@@ -366,55 +461,88 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
     for (uint32_t gi = wave; gi < gpw; gi += kBuildThreads / 64) {
         const uint32_t g = __builtin_amdgcn_readfirstlane(group0 + gi);   // (kept in a vector register otherwise, and the cell arithmetic with it)
         if (g >= n_groups) break;
-        int64_t x = gx[gi], y = gy[gi];
-        int32_t z = (int32_t)((uint32_t)gz[gi] + (lane << s));
         const int k0 = __builtin_amdgcn_readfirstlane(gk[gi]);
         const uint32_t gf = __builtin_amdgcn_readfirstlane(gflag[gi]);
+        int32_t z = (int32_t)((uint32_t)gz[gi] + (lane << s));
         uint64_t zmask = 0ull;                                       // lanes whose z_k was exactly 0 at a rotation before KS
-#pragma unroll
-        for (int k = 1; k < KS; ++k) {
-            if (k >= kcap || k >= k0) {
-                zmask |= __builtin_amdgcn_ballot_w64(z == 0);
-                rot_step(x, y, z, k, plan.lut[k]);
+        int32_t c1, s1, c2, s2;                                      // the entry and its image
+        bool replay = false;                                         // a lane whose image cannot come from the hand-over state
+        if (gf & 2u) {
+            // ---- narrow state: 32-bit words, EXEC-masked add / sub, table tail ----
+            uint32_t x = (uint32_t)gx[gi], y = (uint32_t)gy[gi];
+#define BHW_NARROW(K) if constexpr (K < KS) { if (K >= kcap || K >= k0) rot_narrow<K, true>(x, y, z, zmask, plan.lut[K]); }
+            BHW_NARROW(1) BHW_NARROW(2) BHW_NARROW(3) BHW_NARROW(4) BHW_NARROW(5) BHW_NARROW(6) BHW_NARROW(7) BHW_NARROW(8)
+            BHW_NARROW(9) BHW_NARROW(10) BHW_NARROW(11) BHW_NARROW(12) BHW_NARROW(13) BHW_NARROW(14) BHW_NARROW(15) BHW_NARROW(16)
+            BHW_NARROW(17) BHW_NARROW(18) BHW_NARROW(19) BHW_NARROW(20) BHW_NARROW(21) BHW_NARROW(22) BHW_NARROW(23) BHW_NARROW(24)
+            BHW_NARROW(25)
+#undef BHW_NARROW
+            static_assert(KS <= 26, "unrolled to rotation 25");
+            constexpr uint32_t lowm = (1u << KS) - 1u;
+            const uint32_t zi = (uint32_t)(z + kTailZ);              // own pattern at zi, the image's (z -> -z) at 2 kTailZ - zi
+            const uint32_t mx = (x + 128u) & lowm, my = (y + 128u) & lowm;      // margin of 128 to both ends of the low KS bits
+            const uint32_t unsafe = (uint32_t)((mx < my ? mx : my) < 256u) | (uint32_t)((zi - 1u) >= (uint32_t)(2 * kTailZ - 1));
+            if (__builtin_amdgcn_ballot_w64(unsafe != 0u) == 0ull) {
+                const uint32_t xx = x >> KS, yy = y >> KS;            // < 64: x, y < 2^NITER
+                const uint32_t p1 = tail_p[zi], p2 = tail_p[2u * kTailZ - zi];
+                const int32_t dx1 = tail_d[p1 + yy], dy1 = tail_d[p1 + xx], dx2 = tail_d[p2 + xx], dy2 = tail_d[p2 + yy];
+                c1 = (int32_t)((x - (uint32_t)dx1) >> plan.out_shr);
+                s1 = (int32_t)((y + (uint32_t)dy1) >> plan.out_shr);
+                c2 = (int32_t)((y - (uint32_t)dx2) >> plan.out_shr);
+                s2 = (int32_t)((x + (uint32_t)dy2) >> plan.out_shr);
+            } else {
+                uint32_t x2 = y, y2 = x;
+                int32_t z2 = -z;
+                uint64_t unused = 0ull;
+#define BHW_NARROW(K) if constexpr (K >= KS && K < NITER) { rot_narrow<K, false>(x, y, z, unused, plan.lut[K]); rot_narrow<K, false>(x2, y2, z2, unused, plan.lut[K]); }
+                BHW_NARROW(15) BHW_NARROW(16) BHW_NARROW(17) BHW_NARROW(18) BHW_NARROW(19) BHW_NARROW(20) BHW_NARROW(21) BHW_NARROW(22)
+                BHW_NARROW(23) BHW_NARROW(24) BHW_NARROW(25) BHW_NARROW(26) BHW_NARROW(27) BHW_NARROW(28) BHW_NARROW(29) BHW_NARROW(30)
+                BHW_NARROW(31)
+#undef BHW_NARROW
+                c1 = (int32_t)(x >> plan.out_shr); s1 = (int32_t)(y >> plan.out_shr);
+                c2 = (int32_t)(x2 >> plan.out_shr); s2 = (int32_t)(y2 >> plan.out_shr);
             }
+        } else {
+            // ---- wide state (the first degree of the octant, groups that split early): the 64-bit rotation, rolled ----
+            int64_t x = gx[gi], y = gy[gi];
+#pragma unroll 1
+            for (int k = k0; k < KS; ++k) {
+                zmask |= __builtin_amdgcn_ballot_w64(z == 0);
+                rot_step_dyn(x, y, z, k, lut_s[k], k >= kMad24From);
+            }
+            int64_t x2 = y, y2 = x;
+            int32_t z2 = -z;
+#pragma unroll 1
+            for (int k = KS; k < NITER; ++k) {
+                rot_step_dyn(x, y, z, k, lut_s[k], true);
+                rot_step_dyn(x2, y2, z2, k, lut_s[k], true);
+            }
+            c1 = (int32_t)(x >> plan.out_shr); s1 = (int32_t)(y >> plan.out_shr);
+            c2 = (int32_t)(x2 >> plan.out_shr); s2 = (int32_t)(y2 >> plan.out_shr);
         }
-        int64_t x2 = y, y2 = x;                                      // image chain at rotation KS
-        int32_t z2 = -z;
+        const uint32_t g6 = __builtin_amdgcn_readfirstlane(g << 6);   // back in a scalar register (merged with the branches' copies it
+                                                                      // lands in a vector one, and the wave-uniform cell arithmetic below with it)
+        const uint32_t u = g6 + lane;
+        const bool has_image = u >= 1u && u <= m_last;
         bool deferred = false;                                       // this lane's image goes to the worklist
-        if (zmask != 0ull) {                                         // scalar
-            const uint32_t u_ = (g << 6) + lane;
-            if (((zmask >> lane) & 1ull) != 0ull && u_ >= 1u && u_ <= m_last) {
+        if (zmask != 0ull || gf & 1u) {                              // scalar
+            // z_k == 0 before the hand-over (or, leaf 0, inside the shared prefix): the image is a chain of its own
+            replay = has_image && ((((zmask >> lane) & 1ull) != 0ull) || ((gf & 1u) && lane == 0u));
+            if (replay) {
                 const uint32_t slot = atomicAdd(&work_n, 1u);
-                if (slot < kWorkMax) { work_u[slot] = u_; deferred = true; }
+                if (slot < kWorkMax) { work_u[slot] = u; deferred = true; }
                 else {                                               // list full (never seen): the image chain from scratch, in place
                     int64_t xf = plan.x0, yf = plan.x0;
-                    int32_t zf = (int32_t)(((E - u_) << s) - lut_s[0]);
+                    int32_t zf = (int32_t)(((E - u) << s) - lut_s[0]);
 #pragma unroll 1
-                    for (int r = 1; r < KS; ++r) rot_step(xf, yf, zf, r, lut_s[r]);
-                    x2 = xf; y2 = yf; z2 = zf;
+                    for (int r = 1; r < n_iter; ++r) rot_step_dyn(xf, yf, zf, r, lut_s[r], r >= kMad24From);
+                    c2 = (int32_t)(xf >> plan.out_shr);
+                    s2 = (int32_t)(yf >> plan.out_shr);
                 }
             }
         }
-#pragma unroll
-        for (int k = KS; k < NITER; ++k) {
-            rot_step(x, y, z, k, plan.lut[k]);
-            rot_step(x2, y2, z2, k, plan.lut[k]);
-        }
-        const uint32_t g6 = __builtin_amdgcn_readfirstlane(g << 6);   // back in a scalar register (merged with the zero-event path's copy it
-                                                                      // lands in a vector one, and the wave-uniform cell arithmetic below with it)
-        const uint32_t u = g6 + lane;
         const uint32_t idx = idx_a + g * idx_m;
-        store_entry(idx, (int32_t)(x >> plan.out_shr), (int32_t)(y >> plan.out_shr), record(0, g6 >> d), (g6 & fmask) + lane);
-        int32_t c2 = (int32_t)(x2 >> plan.out_shr), s2 = (int32_t)(y2 >> plan.out_shr);
-        if (gf != 0u && lane == 0u && u >= 1u && u <= m_last) {       // rare (scalar test first): the shared prefix is not mirrored for leaf 0
-            int64_t xf = plan.x0, yf = plan.x0;
-            int32_t zf = (int32_t)(((E - u) << s) - lut_s[0]);
-#pragma unroll 1
-            for (int r = 1; r < n_iter; ++r) rot_step(xf, yf, zf, r, lut_s[r]);
-            c2 = (int32_t)(xf >> plan.out_shr);
-            s2 = (int32_t)(yf >> plan.out_shr);
-        }
-        if (u >= 1u && u <= m_last && !deferred) {
+        store_entry(idx, c1, s1, record(0, g6 >> d), (g6 & fmask) + lane);
+        if (has_image && !deferred) {
             // images E - 64g - 63 .. E - 64g, descending with the lane: one cell, or two when lane 0's image opens the next one
             const uint32_t um = E - u;
             const uint32_t top = E - g6, cell_a = (top - 63u) >> d, cell_b = top >> d;             // wave-uniform
