@@ -73,7 +73,7 @@ def library_sources():
     return srcs
 
 
-def compile_units(objdir, flags=(), jobs=None):
+def compile_units(objdir, flags=(), jobs=None, only=None):
     """hipcc -c of every translation unit (in parallel), gcc -c of the ROM generator; returns (objects, compiler output)."""
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(objdir, exist_ok=True)
@@ -82,10 +82,13 @@ def compile_units(objdir, flags=(), jobs=None):
             "-Rpass-analysis=kernel-resource-usage"] + list(flags)
     jobsl = []
     for unit in ("bhw_api.cpp",) + KERNEL_UNITS:
+        if only and unit not in only:
+            continue
         obj = os.path.join(objdir, os.path.splitext(unit)[0] + ".o")
         jobsl.append((obj, base + ["-x", "hip", "-c", os.path.join(CSRC, unit), "-o", obj]))
     rom_o = os.path.join(objdir, "bhw_rom.o")
-    jobsl.append((rom_o, ["gcc", "-O2", "-fPIC", "-c", os.path.join(CSRC, "bhw_rom.c"), "-o", rom_o]))
+    if not only:
+        jobsl.append((rom_o, ["gcc", "-O2", "-fPIC", "-c", os.path.join(CSRC, "bhw_rom.c"), "-o", rom_o]))
     with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
         outs = list(ex.map(lambda j: _run(j[1]), jobsl))
     return [j[0] for j in jobsl], "\n".join(outs)

@@ -246,52 +246,54 @@ constexpr TailD make_tail_d()
         for (int v = 0; v < 64; ++v) {
             int d = 0;
             for (int j = 0; j < kMirrorTail; ++j) d += ((p >> j) & 1) ? -(v >> j) : (v >> j);   // bit j set: z < 0 at rotation KS + j
-            t.v[p * 64 + v] = (int8_t)d;
+            // stored [v][p]: the 64 leaves of a group share x >> KS and y >> KS (they differ by less than 2^18), so a wave reads one
+            // 64-byte row at 64 patterns -- 16 consecutive dwords, no bank conflict ([p][v] put all 64 lanes on two banks)
+            t.v[v * 64 + p] = (int8_t)d;
         }
     return t;
 }
 __device__ const TailD kTailD = make_tail_d();
 
-// One rotation on the narrow state (see above); K is an immediate, lutk a scalar.  ZERO: also collect z == 0 into zm.
+// One rotation on the narrow state (see above); K is an immediate, lutk a scalar.  Every lane of the wave is active on entry and
+// on exit (phase 2 runs whole groups: EXEC is all ones), so the decision is: v_cmpx (EXEC = lanes with z < 0), three updates,
+// s_not EXEC, three updates, EXEC = -1.  ZERO: zacc = min(zacc, (unsigned)z) -- zero exactly when some z_k was 0 (one VOP2
+// instruction instead of a compare and a scalar OR: the CU's one scalar unit serves four SIMDs, 4.2 cycles per scalar
+// instruction per SIMD against 2.7 for a VOP2, profiles/r03_ubench_issue.txt).
 template <int K, bool ZERO>
-__device__ __forceinline__ void rot_narrow(uint32_t &x, uint32_t &y, int32_t &z, uint64_t &zm, uint32_t lutk)
+__device__ __forceinline__ void rot_narrow(uint32_t &x, uint32_t &y, int32_t &z, uint32_t &zacc, uint32_t lutk)
 {
     uint32_t a, b;
-    uint64_t sv;
     if constexpr (ZERO) {
         asm volatile("v_lshrrev_b32 %[a], %[k], %[y]\n\t"
                      "v_lshrrev_b32 %[b], %[k], %[x]\n\t"
-                     "v_cmp_eq_u32 vcc, 0, %[z]\n\t"
-                     "s_or_b64 %[zm], %[zm], vcc\n\t"
-                     "s_mov_b64 %[sv], exec\n\t"
+                     "v_min_u32 %[za], %[za], %[z]\n\t"
                      "v_cmpx_gt_i32 vcc, 0, %[z]\n\t"
                      "v_add_u32 %[x], %[x], %[a]\n\t"
                      "v_sub_u32 %[y], %[y], %[b]\n\t"
                      "v_add_u32 %[z], %[z], %[l]\n\t"
-                     "s_andn2_b64 exec, %[sv], exec\n\t"
+                     "s_not_b64 exec, exec\n\t"
                      "v_sub_u32 %[x], %[x], %[a]\n\t"
                      "v_add_u32 %[y], %[y], %[b]\n\t"
                      "v_sub_u32 %[z], %[z], %[l]\n\t"
-                     "s_mov_b64 exec, %[sv]"
-                     : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [zm] "+s"(zm), [a] "=&v"(a), [b] "=&v"(b), [sv] "=&s"(sv)
+                     "s_mov_b64 exec, -1"
+                     : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [za] "+v"(zacc), [a] "=&v"(a), [b] "=&v"(b)
                      : [l] "s"(lutk), [k] "n"(K)
-                     : "vcc");
+                     : "vcc", "scc");
     } else {
         asm volatile("v_lshrrev_b32 %[a], %[k], %[y]\n\t"
                      "v_lshrrev_b32 %[b], %[k], %[x]\n\t"
-                     "s_mov_b64 %[sv], exec\n\t"
                      "v_cmpx_gt_i32 vcc, 0, %[z]\n\t"
                      "v_add_u32 %[x], %[x], %[a]\n\t"
                      "v_sub_u32 %[y], %[y], %[b]\n\t"
                      "v_add_u32 %[z], %[z], %[l]\n\t"
-                     "s_andn2_b64 exec, %[sv], exec\n\t"
+                     "s_not_b64 exec, exec\n\t"
                      "v_sub_u32 %[x], %[x], %[a]\n\t"
                      "v_add_u32 %[y], %[y], %[b]\n\t"
                      "v_sub_u32 %[z], %[z], %[l]\n\t"
-                     "s_mov_b64 exec, %[sv]"
-                     : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [a] "=&v"(a), [b] "=&v"(b), [sv] "=&s"(sv)
+                     "s_mov_b64 exec, -1"
+                     : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [a] "=&v"(a), [b] "=&v"(b)
                      : [l] "s"(lutk), [k] "n"(K)
-                     : "vcc");
+                     : "vcc", "scc");
     }
 }
 
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
     __shared__ int32_t gk[kGroupsPerWg];
     __shared__ uint32_t gflag[kGroupsPerWg];                    // bit 0: leaf 0 met z == 0 inside the shared prefix; bit 1: narrow state
     __shared__ uint32_t lut_s[32];
-    __shared__ uint16_t tail_p[2 * kTailZ];                     // z_KS + kTailZ -> 64 * (decision pattern of the tail)
+    __shared__ uint8_t tail_p[2 * kTailZ];                      // z_KS + kTailZ -> decision pattern of the tail
     __shared__ __attribute__((aligned(16))) int8_t tail_d[64 * 64];
     constexpr uint32_t kWorkMax = 512;               // images to run as chains of their own (expected ~40 per workgroup)
     __shared__ uint32_t work_n;
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
         for (int j = 0; j < kMirrorTail; ++j) {
             if (z < 0) { p |= 1u << j; z += (int32_t)plan.lut[KS + j]; } else z -= (int32_t)plan.lut[KS + j];
         }
-        tail_p[zi] = (uint16_t)(p << 6);
+        tail_p[zi] = (uint8_t)p;
     }
     __syncthreads();
 
@@ -470,19 +472,29 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
         if (gf & 2u) {
             // ---- narrow state: 32-bit words, EXEC-masked add / sub, table tail ----
             uint32_t x = (uint32_t)gx[gi], y = (uint32_t)gy[gi];
-#define BHW_NARROW(K) if constexpr (K < KS) { if (K >= kcap || K >= k0) rot_narrow<K, true>(x, y, z, zmask, plan.lut[K]); }
-            BHW_NARROW(1) BHW_NARROW(2) BHW_NARROW(3) BHW_NARROW(4) BHW_NARROW(5) BHW_NARROW(6) BHW_NARROW(7) BHW_NARROW(8)
-            BHW_NARROW(9) BHW_NARROW(10) BHW_NARROW(11) BHW_NARROW(12) BHW_NARROW(13) BHW_NARROW(14) BHW_NARROW(15) BHW_NARROW(16)
-            BHW_NARROW(17) BHW_NARROW(18) BHW_NARROW(19) BHW_NARROW(20) BHW_NARROW(21) BHW_NARROW(22) BHW_NARROW(23) BHW_NARROW(24)
-            BHW_NARROW(25)
+            uint32_t zacc = ~0u;                                      // min over the rotations of (unsigned)z_k: 0 = a zero event
+            // entry at the group's split rotation k0 (17 or 18 at 2^26 / 32 bits): one scalar guard per rotation below kcap, the
+            // first eleven behind one test (a switch with fall-through is lowered to a flag machine that costs 10 us of the pass)
+#define BHW_NARROW(K) if constexpr (K < KS && K < kcap) { if (K >= k0) rot_narrow<K, true>(x, y, z, zacc, plan.lut[K]); }
+            if (k0 < 12) {
+                BHW_NARROW(1) BHW_NARROW(2) BHW_NARROW(3) BHW_NARROW(4) BHW_NARROW(5) BHW_NARROW(6) BHW_NARROW(7) BHW_NARROW(8)
+                BHW_NARROW(9) BHW_NARROW(10) BHW_NARROW(11)
+            }
+            BHW_NARROW(12) BHW_NARROW(13) BHW_NARROW(14) BHW_NARROW(15) BHW_NARROW(16) BHW_NARROW(17) BHW_NARROW(18) BHW_NARROW(19)
 #undef BHW_NARROW
+#define BHW_NARROW(K) if constexpr (K < KS && K >= kcap) rot_narrow<K, true>(x, y, z, zacc, plan.lut[K]);
+            BHW_NARROW(15) BHW_NARROW(16) BHW_NARROW(17) BHW_NARROW(18) BHW_NARROW(19) BHW_NARROW(20) BHW_NARROW(21) BHW_NARROW(22)
+            BHW_NARROW(23) BHW_NARROW(24) BHW_NARROW(25)
+#undef BHW_NARROW
+            zmask = __builtin_amdgcn_ballot_w64(zacc == 0u);
+            static_assert(kPrefixMax == 20, "the switch covers the guarded rotations 1 .. kcap - 1 <= 19");
             static_assert(KS <= 26, "unrolled to rotation 25");
             constexpr uint32_t lowm = (1u << KS) - 1u;
             const uint32_t zi = (uint32_t)(z + kTailZ);              // own pattern at zi, the image's (z -> -z) at 2 kTailZ - zi
             const uint32_t mx = (x + 128u) & lowm, my = (y + 128u) & lowm;      // margin of 128 to both ends of the low KS bits
             const uint32_t unsafe = (uint32_t)((mx < my ? mx : my) < 256u) | (uint32_t)((zi - 1u) >= (uint32_t)(2 * kTailZ - 1));
             if (__builtin_amdgcn_ballot_w64(unsafe != 0u) == 0ull) {
-                const uint32_t xx = x >> KS, yy = y >> KS;            // < 64: x, y < 2^NITER
+                const uint32_t xx = (x >> KS) << 6, yy = (y >> KS) << 6;   // row of D: x, y < 2^NITER, so x >> KS < 64
                 const uint32_t p1 = tail_p[zi], p2 = tail_p[2u * kTailZ - zi];
                 const int32_t dx1 = tail_d[p1 + yy], dy1 = tail_d[p1 + xx], dx2 = tail_d[p2 + xx], dy2 = tail_d[p2 + yy];
                 c1 = (int32_t)((x - (uint32_t)dx1) >> plan.out_shr);
@@ -492,7 +504,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
             } else {
                 uint32_t x2 = y, y2 = x;
                 int32_t z2 = -z;
-                uint64_t unused = 0ull;
+                uint32_t unused = 0u;
 #define BHW_NARROW(K) if constexpr (K >= KS && K < NITER) { rot_narrow<K, false>(x, y, z, unused, plan.lut[K]); rot_narrow<K, false>(x2, y2, z2, unused, plan.lut[K]); }
                 BHW_NARROW(15) BHW_NARROW(16) BHW_NARROW(17) BHW_NARROW(18) BHW_NARROW(19) BHW_NARROW(20) BHW_NARROW(21) BHW_NARROW(22)
                 BHW_NARROW(23) BHW_NARROW(24) BHW_NARROW(25) BHW_NARROW(26) BHW_NARROW(27) BHW_NARROW(28) BHW_NARROW(29) BHW_NARROW(30)

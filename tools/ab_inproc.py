@@ -18,12 +18,22 @@ def build_variant(idx, flags):
     # variants are cached under build/ab/ by (flags, source hash): prebuild them in the CPU container with --build-only,
     # the snapshot carries them to the GPU box (GPU minutes are not spent compiling)
     import hashlib
-    tag = hashlib.sha256((flags + _build._digest(_build.library_sources())).encode()).hexdigest()[:16]
+    tag = hashlib.sha256((flags + os.environ.get("AB_UNITS", "") * bool(flags) + _build._digest(_build.library_sources())).encode()).hexdigest()[:16]
     out = os.path.join(ROOT, "build", "ab", f"libbhw_{tag}.so")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     if os.path.exists(out):
         return out
-    objects, _ = _build.compile_units(os.path.join(ROOT, "build", "ab", "obj_" + tag), flags.split())
+    objdir = os.path.join(ROOT, "build", "ab", "obj_" + tag)
+    units = os.environ.get("AB_UNITS")            # e.g. "bhw_build.hip": only these units see the flags, the rest are the "" variant's objects
+    if units and flags:
+        base = build_variant(idx, "")
+        base_tag = os.path.basename(base)[len("libbhw_"):-3]
+        objects, _ = _build.compile_units(objdir, flags.split(), only=units.split(","))
+        have = {os.path.basename(o) for o in objects}
+        base_dir = os.path.join(ROOT, "build", "ab", "obj_" + base_tag)
+        objects += [os.path.join(base_dir, f) for f in sorted(os.listdir(base_dir)) if f.endswith(".o") and f not in have]
+    else:
+        objects, _ = _build.compile_units(objdir, flags.split())
     _build.link_library(objects, out)
     return out
 
@@ -71,6 +81,11 @@ def main():
             return L.bhw_generate_part_device(ctypes.byref(p), 0, ctypes.c_void_p(st), 1, parts, ctypes.c_void_p(out.data_ptr()), None)
         return L.bhw_generate_device(ctypes.byref(p), 0, ctypes.c_void_p(st), 0, n, ctypes.c_void_p(out.data_ptr()))
 
+    if os.environ.get("AB_FORCE_NIBBLE"):                 # timing experiments that corrupt the table values: pin the format verdict
+        for L in libs:
+            d = ctypes.c_uint32(0)
+            L.bhw_dbg_table_format_info(ctypes.byref(p), ctypes.byref(d), None)
+            L.bhw_dbg_table_format_verdict(ctypes.byref(p), ctypes.c_uint32(16 + d.value), 1)
     ref = None
     for L in libs:
         out.zero_()
