@@ -6,7 +6,8 @@ Blackman-Harris 7-term, N = 2^26 (64M points), 32-bit output (BASELINE.json conf
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One process per GPU.  A step = one pass of the hot path over one batch: 2^26 coefficients generated
+Without WORLD_SIZE in the environment `python bench.py --gpus N` (N > 1) starts its N ranks itself (a torch.distributed.run child
+process, before this process touches a GPU).  One process per GPU.  A step = one pass of the hot path over one batch: 2^26 coefficients generated
 from the parameter set into a resident HBM buffer (no inputs; nothing cached between steps: the
 shared CORDIC table is rebuilt inside every step).  With N ranks the coefficient stream is sharded by
 contiguous index range -- rank r produces stream indices [r*2^26, (r+1)*2^26) -- with no data-path
@@ -123,6 +124,48 @@ def pmc_traffic():
     return float(d["_step_hbm_bytes"]), src
 
 
+def self_launch(n_ranks, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE: run the N ranks as children of this process (torch.distributed.run on
+    127.0.0.1) and return their exit code.  Called before anything in this process has initialised a GPU; the ranks are new
+    processes, nothing is re-exec'ed."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")         # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_check(args, rank, world):
+    """--launch-check: the N>1 plumbing without a GPU (tests/test_distributed.py): process group over gloo, the timing protocol
+    on a sleeping step, rank 0 prints the JSON line."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+
+    def allreduce_max(v):
+        if world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    elapsed = timed_steps(lambda: time.sleep(0.002 * (rank + 1)), args.steps, args.warmup,
+                          dist.barrier if world > 1 else (lambda: None), lambda: None, allreduce_max)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": args.scaling,
+                          "ms_per_step": elapsed / args.steps * 1e3, "shard_of_last_rank": list(shard_for(world - 1))}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def device_times(step, steps, torch):
     """Per-step device time (ms) of `steps` back-to-back steps: one HIP event before each step and one after the last, on
     the stream the kernels are launched on.  Outside the timed region (the extra events would perturb it)."""
@@ -133,6 +176,87 @@ def device_times(step, steps, torch):
     evs[steps].record()
     torch.cuda.synchronize()
     return [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+
+
+def extra_legs(torch, bhw, B, out, steps):
+    """Untimed legs for the other BASELINE configurations and for the variants DESIGN.md quotes, each measured like the headline's
+    device time: a short ramp, then the median of per-step HIP-event intervals on the launch stream (short windows: 20 calls
+    captured into one HIP graph, per-window time = replay time / 20, so the host's ~7 us per call is not in the figure).
+    {ms, GB/s, frac, plan} per leg; bytes = 4 B per coefficient written (fused apply: 8 B, x read + y written)."""
+    legs = {}
+
+    def measure(fn, n_coeff, plan, bytes_per=BYTES_PER_COEFF, note=None, reps=None):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.25:                  # the previous leg's read-backs let the clocks drop
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
+        reps = reps or min(max(steps, 10), 50)
+        batches = []
+        for _ in range(5):                                      # like the headline's device time: events around back-to-back steps
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            batches.append(e0.elapsed_time(e1) / reps)
+        ms = statistics.median(batches)
+        gbs = bytes_per * n_coeff / (ms * 1e-3) / 1e9
+        leg = {"ms": ms, "GB/s": gbs, "frac": gbs / HBM_PEAK_GBS, "Gsamples_per_s": n_coeff / (ms * 1e-3) / 1e9,
+               "plan": plan() if callable(plan) else plan}
+        if note:
+            leg["note"] = note
+        return leg
+
+    n26 = 1 << 26
+    # BASELINE configs[1]: BH-4, N = 2^20, 24-bit -- per call, and per window inside a 20-call HIP graph
+    p2 = bhw.make_params(4, 20, 24)
+    bhw.prepare(p2)
+    o2 = out[:1 << 20]
+    plan2 = B.describe_plan(p2, 0, 1 << 20, B.ALGO_AUTO)
+    legs["C2_bh4_2^20_24bit_per_call"] = measure(lambda: bhw.generate(p2, 0, 1 << 20, out=o2), 1 << 20, plan2,
+                                                 note="back-to-back calls from Python: includes the host's per-call cost", reps=200)
+    try:
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            bhw.generate(p2, 0, 1 << 20, out=o2)
+            st.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                for _ in range(20):
+                    bhw.generate(p2, 0, 1 << 20, out=o2)
+            leg = measure(g.replay, 20 << 20, plan2, note="20 windows per HIP-graph replay; ms = per window", reps=50)
+        leg["ms"] /= 20.0
+        legs["C2_bh4_2^20_24bit_graph"] = leg
+    except Exception as e:                                       # graph capture unavailable: the per-call figure stands
+        legs["C2_bh4_2^20_24bit_graph"] = {"error": repr(e)}
+    # BASELINE configs[3]: 1024 frames x BH-4 N = 2^16, 24-bit (one period computed, then store-only replication)
+    p4 = bhw.make_params(4, 16, 24)
+    o4 = out.view(1024, 1 << 16)
+    legs["C4_1024x_bh4_2^16_24bit"] = measure(lambda: bhw.generate_batched(p4, 1024, out=o4), n26,
+                                              lambda: B.describe_plan(p4, 0, 1 << 16, B.ALGO_AUTO) + " + k_replicate16")
+    # phase bits dropped (models A / C at PHASE_WIDTH > DATA_WIDTH): run-length kernel
+    pn = bhw.make_params(WIN, PHI_WIDTH, 16, model=B.MODEL_CPP)
+    legs["bh7_2^26_16bit_cpp"] = measure(lambda: bhw.generate(pn, 0, n26, out=out), n26, lambda: B.describe_plan(pn, 0, n26, B.ALGO_AUTO))
+    # Taylor source (win_selector wires it to Hamming / BH-3 only)
+    pt = bhw.make_params(1, PHI_WIDTH, 16, sin_type=B.SIN_TAYLOR, combine=B.COMBINE_VHDL, lut_size=9)
+    legs["taylor_hamming_2^26_16bit"] = measure(lambda: bhw.generate(pt, 0, n26, out=out), n26, lambda: B.describe_plan(pt, 0, n26, B.ALGO_AUTO))
+    # the headline window with the VHDL cosine-sum (src/bh_win_7term.vhd:353-438: what win_selector instantiates)
+    pv = bhw.make_params(WIN, PHI_WIDTH, DAT_WIDTH, combine=B.COMBINE_VHDL)
+    legs["C3_vhdl_cosine_sum"] = measure(lambda: bhw.generate(pv, 0, n26, out=out), n26, lambda: B.describe_plan(pv, 0, n26, B.ALGO_AUTO))
+    # ... and with the VHDL CORDIC as well (model C end to end)
+    pvv = bhw.make_params(WIN, PHI_WIDTH, DAT_WIDTH, model=B.MODEL_VHDL, combine=B.COMBINE_VHDL)
+    legs["C3_vhdl_cordic_and_sum"] = measure(lambda: bhw.generate(pvv, 0, n26, out=out), n26, lambda: B.describe_plan(pvv, 0, n26, B.ALGO_AUTO))
+    # fused apply y = (x * w) >> 31 (SURVEY 8f rank 1): reads x, writes y, no coefficient vector in HBM
+    x = torch.randint(-(1 << 31), (1 << 31) - 1, (n26,), dtype=torch.int32, device=out.device)
+    p3 = bhw.make_params(WIN, PHI_WIDTH, DAT_WIDTH)
+    legs["fused_apply_C3"] = measure(lambda: bhw.apply(p3, x, out=out, shift=31), n26, lambda: "bhw_apply_device: " + B.describe_plan(p3, 0, n26, B.ALGO_AUTO),
+                                     bytes_per=8, note="8 B per sample: x read + y written")
+    del x
+    return legs
 
 
 def spread(ms):
@@ -158,17 +282,25 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for the barrier / max-over-ranks (nccl = RCCL; gloo only to rehearse N>1 "
                          "on a box with fewer GPUs than ranks, together with BHW_BENCH_SHARE_GPU=1)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the untimed legs for the other BASELINE configurations")
+    ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))           # this process has not touched a GPU
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
+                         "(or leave WORLD_SIZE unset: bench.py then starts its ranks itself)")
+    if args.launch_check:
+        return launch_check(args, rank, world)
 
     import torch
     import blackman_harris_win_amd as bhw
     from blackman_harris_win_amd import binding as B
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the generator has no CPU path)")
     if os.environ.get("BHW_BENCH_SHARE_GPU") == "1":        # rehearsal only: all ranks on one GPU
@@ -282,22 +414,32 @@ def main():
     # (tests/golden/golden.json, C3: sparse samples, per-shard sums and 8 x 1024 strided samples); the full
     # bit-for-bit comparison with the oracle is tests/test_gpu_parity.py
     parity = None
-    try:
-        with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
-            g = json.load(f)["entries"]["C3_bh7_26_32"]
-        step_s = (1 << 23) // 1024
-        if strong and world > 1:
-            # this rank holds only its segments: every golden sample inside them must match
+    step_s = (1 << 23) // 1024
+    if strong and world > 1:
+        # this rank holds only its segments: every golden sample inside them must match.  Every rank reaches the collective
+        # whatever happened to it (a mismatch or a missing fixture on one rank must not leave the others waiting in it).
+        bad = 0.0
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
+                g = json.load(f)["entries"]["C3_bh7_26_32"]
             owned = torch.zeros(COUNT, dtype=torch.bool, device=dev)
             for s0, c in segments:
                 owned[s0:s0 + c] = True
-            parity = True
             for sh, e in enumerate(g["shards"]):
                 idx = (sh << 23) + step_s * torch.arange(1024, device=dev)
                 want = torch.tensor(e["strided_1024"], dtype=torch.int32, device=dev)
                 m = owned[idx]
-                parity = parity and bool((out[idx][m] == want[m]).all())
-            parity = bool(parity) and allreduce_max(0.0 if parity else 1.0) == 0.0
+                if not bool((out[idx][m] == want[m]).all()):
+                    bad = 1.0
+        except Exception:
+            bad = 2.0
+        worst = allreduce_max(bad)
+        parity = None if worst == 2.0 else worst == 0.0
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
+            g = json.load(f)["entries"]["C3_bh7_26_32"]
+        if strong and world > 1:
+            pass
         else:
             parity = all(int(out[int(n)]) == v for n, v in g["sparse"].items())
             for sh, e in enumerate(g["shards"]):
@@ -329,6 +471,15 @@ def main():
                    "note": "same window, CORDIC bit-model of cpp/cordic_sincos.cpp (BHW_MODEL_CPP) in the HLS cosine-sum; device time"}
         step()                                                  # leave the headline window in `out`
 
+    legs = None
+    if not strong and rank == 0 and world == 1 and not args.no_extra_legs:
+        legs = extra_legs(torch, bhw, B, out, args.steps)
+        if cpp_leg:
+            gbs = BYTES_PER_COEFF * count / (cpp_leg["ms_per_step_median"] * 1e-3) / 1e9
+            legs["C3_model_cpp"] = {"ms": cpp_leg["ms_per_step_median"], "GB/s": gbs, "frac": gbs / HBM_PEAK_GBS,
+                                    "Gsamples_per_s": cpp_leg["Gsamples_per_s"], "plan": cpp_leg["plan"]}
+        step()
+
     total = units_per_step * args.steps
     value = total / elapsed / 1e9
     # roofline: algorithmic bytes of what THIS device wrote per step / its device time per step
@@ -357,6 +508,7 @@ def main():
         "ramp": {"seconds": args.ramp_seconds, "steps": ramp_steps},
         "parity_spot_check": parity,
         "cpp_model": cpp_leg,
+        "extra_legs": legs,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         rec["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.cpu_threads)

@@ -23,11 +23,11 @@ from .binding import (  # noqa: F401
     BhwAtan2Params, BhwError, BhwParams, coeffs_from_float, constant_tables, lib, lib_path, make_params, part_segments,
 )
 from .selector import (  # noqa: F401
-    WinSelector, apply, atan2, cordic, generate, generate_batched, generate_part, prepare, shard_range, win_function,
+    WinSelector, apply, atan2, cordic, gather_parts, generate, generate_batched, generate_part, prepare, shard_range, win_function,
 )
 
 __all__ = [
-    "WinSelector", "win_function", "cordic", "atan2", "generate", "generate_batched", "generate_part", "part_segments", "apply",
+    "WinSelector", "win_function", "cordic", "atan2", "generate", "generate_batched", "generate_part", "gather_parts", "part_segments", "apply",
     "prepare", "shard_range",
     "make_params", "coeffs_from_float", "constant_tables", "BhwParams", "BhwError", "lib", "lib_path",
 ]

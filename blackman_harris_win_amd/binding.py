@@ -10,7 +10,7 @@ SIN_CORDIC, SIN_TAYLOR, SIN_TAYLOR_ALL = 0, 1, 2
 WIN_HAMMING, WIN_HANN, WIN_BH3, WIN_BH4, WIN_BH5, WIN_BH7 = 1, 2, 3, 4, 5, 7
 ALGO_AUTO, ALGO_DIRECT, ALGO_TABLE, ALGO_FUSED = 0, 1, 2, 3
 TABLE_BEST, TABLE_PLAIN, TABLE_DELTA16, TABLE_RESIDUAL, TABLE_NIBBLE = 0, 1, 2, 3, 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/bhw.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
@@ -19,6 +19,7 @@ ABI_SYMBOLS = (
     "bhw_workspace_bytes", "bhw_generate_batched_device", "bhw_sincos_device", "bhw_generate_to_host",
     "bhw_sincos_to_host", "bhw_release_device", "bhw_apply_device", "bhw_atan2_device", "bhw_atan2_to_host",
     "bhw_prepare_device", "bhw_part_segments", "bhw_generate_part_device", "bhw_describe_plan",
+    "bhw_coeffs_preset", "bhw_gather_parts_device",
 )
 
 
@@ -90,6 +91,8 @@ def lib():
     L.bhw_params_validate.argtypes = [P]
     L.bhw_coeffs_from_float.argtypes = [u32, u32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]
     L.bhw_constant_tables.argtypes = [u32, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+    L.bhw_coeffs_preset.argtypes = [u32, u32, ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]
+    L.bhw_gather_parts_device.argtypes = [P, u32, ctypes.POINTER(ci), ctypes.POINTER(vp), ci, vp, i32p]
     L.bhw_generate_device.argtypes = [P, ci, vp, u64, u64, i32p]
     L.bhw_generate_device_ex.argtypes = [P, ci, vp, u64, u64, i32p, ctypes.POINTER(BhwExec)]
     L.bhw_workspace_bytes.restype = u64
@@ -146,6 +149,19 @@ def coeffs_from_float(win_type, dat_width, a=None):
         arr = (ctypes.c_double * 7)(*(list(a) + [0.0] * (7 - len(a))))
     check(lib().bhw_coeffs_from_float(win_type, dat_width, arr, aa))
     return list(aa)
+
+
+PRESETS = {"nuttall": 1, "blackman-nuttall": 2, "flat-top-1": 3, "flat-top-2": 4, "bh7-readme": 5, "blackman": 6, "bh3": 7}
+
+
+def coeffs_preset(name, dat_width):
+    """(win_type, float weights, integer weights) of a named coefficient set the reference lists beside its built-ins
+    (bhw_coeffs_preset: hls/windows/win_function.cpp:241-250,292-303, README.md:30-51)."""
+    wt = ctypes.c_uint32(0)
+    a = (ctypes.c_double * 7)()
+    aa = (ctypes.c_int32 * 7)()
+    check(lib().bhw_coeffs_preset(PRESETS[name] if isinstance(name, str) else int(name), dat_width, ctypes.byref(wt), a, aa))
+    return int(wt.value), list(a), list(aa)
 
 
 def constant_tables(which):

@@ -331,7 +331,9 @@ uint32_t pick_algo(const bhw_params *p, const BhwCordicCfg &c, uint64_t n0, uint
     const bool fused_ok = bhwk_fold_direct_applicable(c) && has_whole_period(p, n0, count);
     if (requested == BHW_ALGO_FUSED) return fused_ok ? BHW_ALGO_FUSED : BHW_ALGO_TABLE;
     if (requested == BHW_ALGO_DIRECT || requested == BHW_ALGO_TABLE) return requested;
-    if (fused_ok && p->phi_width <= fused_max_pw(p->n_terms)) return BHW_ALGO_FUSED;
+    // (with dropped phase bits the table has only 2^(W-2) entries and the run-length kernel runs at the store rate: the crossover
+    // above was measured at z_shr == 0 only, so such windows keep the table strategy once they are long enough for that kernel)
+    if (fused_ok && p->phi_width <= fused_max_pw(p->n_terms) && (c.z_shr == 0 || p->phi_width < 15)) return BHW_ALGO_FUSED;
     const uint64_t chains_direct = count * (p->n_terms - 1);
     return chains_direct >= 2 * table_entries(c) ? BHW_ALGO_TABLE : BHW_ALGO_DIRECT;
 }
@@ -590,6 +592,27 @@ int bhw_coeffs_from_float(uint32_t win_type, uint32_t dat_width, const double *a
     return BHW_OK;
 }
 
+int bhw_coeffs_preset(uint32_t preset, uint32_t dat_width, uint32_t *win_type, double a[7], int32_t aa[7])
+{
+    // hls/windows/win_function.cpp:241-250 (Nuttall, Blackman-Nuttall), :292-303 (flat-top 1 / 2), README.md:30-51
+    static const struct { uint32_t win; double a[7]; } kPresets[] = {
+        {0, {0}},
+        {BHW_WIN_BH4, {0.355768, 0.487396, 0.144232, 0.012604}},
+        {BHW_WIN_BH4, {0.3635819, 0.4891775, 0.1365995, 0.0106411}},
+        {BHW_WIN_BH5, {0.25, 0.4925, 0.3225, 0.097, 0.0075}},
+        {BHW_WIN_BH5, {0.215578950, 0.416631580, 0.277263158, 0.083578947, 0.006947368}},
+        {BHW_WIN_BH7, {0.27105140069342, 0.43329793923448, 0.21812299954311, 0.06592544638803, 0.01081174209837,
+                       0.00077658482522, 0.00001388721735}},
+        {BHW_WIN_BH3, {0.42, 0.5, 0.08}},
+        {BHW_WIN_BH3, {0.42323, 0.49755, 0.07922}},
+    };
+    if (preset < 1 || preset >= sizeof kPresets / sizeof kPresets[0]) return fail(BHW_ERR_BADARG, "preset %u", preset);
+    if (win_type) *win_type = kPresets[preset].win;
+    if (a) memcpy(a, kPresets[preset].a, 7 * sizeof(double));
+    if (aa) return bhw_coeffs_from_float(kPresets[preset].win, dat_width, kPresets[preset].a, aa);
+    return BHW_OK;
+}
+
 int bhw_params_init(bhw_params *p, uint32_t win_type, uint32_t phi_width, uint32_t dat_width)
 {
     if (!p) return fail(BHW_ERR_BADARG, "params is NULL");
@@ -694,6 +717,9 @@ int bhw_describe_plan(const bhw_params *p, uint64_t n0, uint64_t count, const bh
     }
     char build[64], combine[64];
     bhwk_describe_table(c, w, tiled, build, combine, sizeof build);
+    if (period && c.tab_dlog == 0 && bhwk_runlength_applicable(c, w, nullptr))     // generate_impl's period(): dropped phase bits
+        snprintf(combine, sizeof combine, "k_runlength_window<%u,%d,%s>", p->n_terms, (w.combine != BHW_COMBINE_HLS) ? 2 : (c.ones_neg ? 1 : 0),
+                 c.dat_width <= 16 ? "true" : "false");
     const char *fmt = c.tab_dlog == 0 ? "plain" : c.tab_dlog == 6 ? "delta16" : c.tab_dlog >= 16 ? "nibble" : "residual";
     snprintf(buf, len, "table[%s%s]: %s + %s%s", fmt, state, build, (period || images) ? combine : "k_table_combine",
              images ? " (image subset)" : period && count != (1ull << p->phi_width) ? " (+ k_table_combine / k_replicate on the rest)" : "");
@@ -956,6 +982,15 @@ int part_checks(const bhw_params *p, uint32_t part, uint32_t n_parts)
     if (p->sin_type != BHW_SIN_CORDIC) return fail(BHW_ERR_UNSUPPORTED, "interleaved parts exist for the CORDIC source only");
     if (n_parts < 1 || n_parts > 64 || part >= n_parts) return fail(BHW_ERR_BADARG, "part %u of %u (1..64 parts)", part, n_parts);
     if (p->phi_width < 9) return fail(BHW_ERR_UNSUPPORTED, "interleaved parts need phi_width >= 9 (a ring of 64 lanes)");
+    // a part is produced by the fused kernel (CORDIC state within 34 bits) or by the tile kernel over the full table (N >= 2^22):
+    // configurations with neither (e.g. VHDL model, W = 32, PRECISION >= 3 below 2^22) have no part kernel, and the segment
+    // arithmetic must not promise what bhw_generate_part_device cannot deliver
+    BhwCordicCfg c;
+    resolve_cordic(p, c);
+    BhwWinCfg w;
+    resolve_window(p, w);
+    if (!bhwk_fold_direct_applicable(c) && !bhwk_tile_applicable(c, w))
+        return fail(BHW_ERR_UNSUPPORTED, "no kernel produces ownership parts of this configuration (CORDIC state beyond 34 bits and no tile plan)");
     return BHW_OK;
 }
 } // namespace
@@ -1062,6 +1097,34 @@ int bhw_generate_part_device(const bhw_params *p, int device, void *hip_stream, 
     return e ? fail_hip(e, "tile part launch") : BHW_OK;
 }
 
+int bhw_gather_parts_device(const bhw_params *p, uint32_t n_parts, const int *src_devices, const int32_t *const *d_windows,
+                            int dst_device, void *dst_stream, int32_t *d_dst)
+{
+    int rc = part_checks(p, 0, n_parts);
+    if (rc) return rc;
+    if (!src_devices || !d_windows || !d_dst) return fail(BHW_ERR_BADARG, "src_devices / d_windows / d_dst is NULL");
+    if (!device_ok(dst_device)) return fail(BHW_ERR_HIP, "no usable HIP device %d (this library has no CPU path)", dst_device);
+    for (uint32_t g = 0; g < n_parts; ++g) {
+        if (!d_windows[g]) return fail(BHW_ERR_BADARG, "d_windows[%u] is NULL", g);
+        if (!device_ok(src_devices[g])) return fail(BHW_ERR_HIP, "no usable HIP device %d", src_devices[g]);
+    }
+    DeviceGuard guard(dst_device);
+    if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
+    std::vector<bhw_segment> segs(256);
+    for (uint32_t g = 0; g < n_parts; ++g) {
+        if (d_windows[g] == d_dst) continue;                      // this part was generated in place
+        uint32_t n = 0;
+        rc = bhw_part_segments(p, g, n_parts, segs.data(), (uint32_t)segs.size(), &n);
+        if (rc) return rc;
+        for (uint32_t i = 0; i < n; ++i) {
+            const hipError_t e = hipMemcpyPeerAsync(d_dst + segs[i].n0, dst_device, d_windows[g] + segs[i].n0, src_devices[g],
+                                                    segs[i].count * sizeof(int32_t), (hipStream_t)dst_stream);
+            if (e != hipSuccess) return fail_hip(e, "hipMemcpyPeerAsync(segment)");
+        }
+    }
+    return BHW_OK;
+}
+
 int bhw_release_device(int device)
 {
     DeviceScratch taken;
@@ -1102,6 +1165,9 @@ int bhw_prepare_device(const bhw_params *p, int device, void *hip_stream)
     resolve_cordic(p, c);
     BhwWinCfg w;
     resolve_window(p, w);
+    // whole periods are what prepared callers replay; a configuration AUTO sends to the fused or direct kernel needs no scratch
+    const uint64_t N = 1ull << p->phi_width;
+    if (pick_algo(p, c, 0, N, BHW_ALGO_AUTO) != BHW_ALGO_TABLE) return BHW_OK;
     const uint64_t need = table_entries(c) * 8ull;
     auto slot = slot_of(device, hip_stream);
     std::unique_lock<std::mutex> lk(slot->mu);

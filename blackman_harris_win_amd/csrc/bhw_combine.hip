@@ -826,7 +826,7 @@ bool bhwk_runlength_applicable(const BhwCordicCfg &c, const BhwWinCfg &w, const 
     if (((w.n_terms - 1u) * (uint32_t)kRlRun) > (1u << c.z_shr)) return false;
     if (c.phi_width - 2u - c.z_shr < 2u) return false;                            // H a multiple of 2^z_shr
     if (w.combine != BHW_COMBINE_HLS && c.dat_width > 28) return false;
-    return (((uintptr_t)d_out) & 15u) == 0;
+    return (((uintptr_t)d_out) & 15u) == 0;                                       // (NULL: the caller asks about the configuration only)
 }
 
 int bhwk_runlength_window(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out)

@@ -101,10 +101,27 @@ def generate_part(params, part, n_parts, window, *, algo=B.ALGO_AUTO, workspace=
     a full-length (2^phi_width) int32 CUDA tensor; every other element is left untouched.  binding.part_segments lists them."""
     torch = _torch()
     dev = _check_out(torch, window, 1 << params.phi_width, "window")
+    if workspace is not None and workspace.device.index != dev:
+        raise ValueError("workspace must live on the window's device")
     ex = _exec(algo, workspace, event_after_build, table_format)
     B.check(B.lib().bhw_generate_part_device(ctypes.byref(params), dev, _stream_ptr(torch, dev), int(part), int(n_parts),
                                               ctypes.c_void_p(window.data_ptr()), ctypes.byref(ex)))
     return window
+
+
+def gather_parts(params, windows, out):
+    """One window on out's device from its interleaved ownership parts (bhw_gather_parts_device): windows[g] is the full-length
+    int32 CUDA tensor part g of len(windows) was generated into (any device; windows[g] may be `out` itself).  Peer copies of the
+    owned segments on out's current stream; the producing streams must have been synchronised with it by the caller."""
+    torch = _torch()
+    n = 1 << params.phi_width
+    dev = _check_out(torch, out, n)
+    G = len(windows)
+    devs = (ctypes.c_int * G)(*[_check_out(torch, w, n, "window") for w in windows])
+    ptrs = (ctypes.c_void_p * G)(*[w.data_ptr() for w in windows])
+    B.check(B.lib().bhw_gather_parts_device(ctypes.byref(params), G, devs, ptrs, dev, _stream_ptr(torch, dev),
+                                             ctypes.c_void_p(out.data_ptr())))
+    return out
 
 
 def apply(params, x, *, n0=0, shift=None, out=None):

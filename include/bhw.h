@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BHW_ABI_VERSION 2u
+#define BHW_ABI_VERSION 3u   /* 3: bhw_coeffs_preset, bhw_gather_parts_device added (nothing removed or changed) */
 
 /* CORDIC bit-model (the reference holds three that are not bit-identical). */
 enum {
@@ -126,6 +126,22 @@ int bhw_params_validate(const bhw_params *p);
  * the built-in constants of `win_type`.  Host arithmetic only (doubles -> 7 integers). */
 int bhw_coeffs_from_float(uint32_t win_type, uint32_t dat_width, const double *a, int32_t aa[7]);
 
+/* The named coefficient sets the reference lists beside its built-in ones (comments in hls/windows/win_function.cpp:241-250 and
+ * :292-303, README.md:30-51): the float weights a[0..6] (unused terms 0), the window type that takes them, and -- when aa != NULL
+ * -- the integer weights of the HLS derivation above for dat_width (bhw_coeffs_from_float(*win_type, dat_width, a, aa)).
+ * Two upstream slips are not reproduced: the Nuttall a2 is the published 0.144232 (win_function.cpp:244 prints 0.144323, with
+ * which the weights no longer sum to one), and flat-top (2) lists its fifth weight as a second "a3" (:302-303). */
+enum {
+    BHW_PRESET_NUTTALL          = 1,  /* 4-term: 0.355768, 0.487396, 0.144232, 0.012604                 -93 dB (README.md:35) */
+    BHW_PRESET_BLACKMAN_NUTTALL = 2,  /* 4-term: 0.3635819, 0.4891775, 0.1365995, 0.0106411             -98 dB (README.md:37) */
+    BHW_PRESET_FLATTOP_1        = 3,  /* 5-term: 0.25, 0.4925, 0.3225, 0.097, 0.0075  (win_function.cpp:292-297)             */
+    BHW_PRESET_FLATTOP_2        = 4,  /* 5-term: 0.21557895, 0.41663158, 0.277263158, 0.083578947, 0.006947368 (:298-303)   */
+    BHW_PRESET_BH7_README       = 5,  /* 7-term set of README.md:45-51 ("up to 180 dB")                                      */
+    BHW_PRESET_BLACKMAN         = 6,  /* 3-term: 0.42, 0.5, 0.08                                         -58 dB (README.md:32) */
+    BHW_PRESET_BH3              = 7   /* 3-term Blackman-Harris: 0.42323, 0.49755, 0.07922               -71 dB (README.md:33) */
+};
+int bhw_coeffs_preset(uint32_t preset, uint32_t dat_width, uint32_t *win_type, double a[7], int32_t aa[7]);
+
 /* The 48-entry arctangent ROMs and gains the kernels use (which: 0 = T2 of the cpp model,
  * 1 = T4 of the HLS/VHDL models); gains[0] = G46, gains[1] = G47. */
 int bhw_constant_tables(uint32_t which, int64_t table[48], int64_t gains[2]);
@@ -174,6 +190,15 @@ typedef struct bhw_segment {
 int bhw_part_segments(const bhw_params *p, uint32_t part, uint32_t n_parts, bhw_segment *segs, uint32_t capacity, uint32_t *n_segs);
 int bhw_generate_part_device(const bhw_params *p, int device, void *hip_stream, uint32_t part, uint32_t n_parts,
                              int32_t *d_window, const bhw_exec *ex);
+
+/* One window on one device from its `n_parts` interleaved ownership parts (optional, outside the metric).  Part g
+ * was produced by bhw_generate_part_device(p, src_devices[g], ..., g, n_parts, d_windows[g]) into a full-length buffer on
+ * src_devices[g]; every segment part g owns (bhw_part_segments) is copied into d_dst, a full-length buffer on dst_device, with
+ * hipMemcpyPeerAsync on dst_stream (xGMI between devices; a plain device copy where source and destination coincide; nothing
+ * is copied when d_windows[g] == d_dst).  The caller orders dst_stream after the producing streams (an event per part, or a
+ * device synchronise); no collective and no host staging are involved. */
+int bhw_gather_parts_device(const bhw_params *p, uint32_t n_parts, const int *src_devices, const int32_t *const *d_windows,
+                            int dst_device, void *dst_stream, int32_t *d_dst);
 
 /* Fused apply (the step after the path in every consumer -- the window multiplies the samples in
  * front of an FFT).  d_y[i] = (d_x[i] * w[n0+i]) >> shift with the exact 64-bit product (as int_multNxN_dsp48,

@@ -106,6 +106,22 @@ public:
     {
         check(bhw_generate_part_device(&p_, device_, stream, part, n_parts, d_window, nullptr));
     }
+    // the whole window on this selector's device from its n_parts parts (d_windows[g] on src_devices[g]): peer copies of the
+    // owned segments, no collective (bhw_gather_parts_device)
+    void GATHER_PARTS(uint32_t n_parts, const int *src_devices, const int32_t *const *d_windows, int32_t *d_dst, void *stream = nullptr)
+    {
+        check(bhw_gather_parts_device(&p_, n_parts, src_devices, d_windows, device_, stream, d_dst));
+    }
+    // AA0..AA6 from one of the named coefficient sets of the reference's comments / README (bhw_coeffs_preset); the window
+    // type must be the preset's
+    void AA_PRESET(uint32_t preset)
+    {
+        uint32_t wt = 0;
+        int32_t aa[7];
+        check(bhw_coeffs_preset(preset, p_.dat_width, &wt, nullptr, aa));
+        if (wt != p_.win_type) throw error(BHW_ERR_BADARG, "preset belongs to another window type");
+        for (int k = 0; k < 7; ++k) p_.aa[k] = aa[k];
+    }
     const bhw_params &params() const { return p_; }
 
 private:

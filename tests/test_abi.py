@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_loads_and_exports_every_declared_symbol():
     L = B.lib()
-    assert L.bhw_abi_version() == 2
+    assert L.bhw_abi_version() == 3
     header = open(os.path.join(ROOT, "include", "bhw.h")).read()
     declared = set(re.findall(r"\b(bhw_[a-z_0-9]+)\s*\(", header))
     assert declared == set(B.ABI_SYMBOLS)
@@ -164,3 +164,55 @@ def test_headline_kernels_have_no_scratch():
         assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0, (name, r)
     for name in ("k_table_combine_tile<15, 0, 3, true, false>", "k_table_combine_tile<15, 0, 2, true, false>"):
         assert res[name]["VGPRs"] <= 64 and res[name]["LDS Size"] <= 80 * 1024, (name, res[name])   # two 960-thread workgroups per CU
+
+
+def test_coefficient_presets():
+    """bhw_coeffs_preset: the named sets of hls/windows/win_function.cpp:241-250,292-303 and README.md:30-51, scaled by the HLS rule."""
+    from blackman_harris_win_amd import binding as B
+    wt, a, aa = B.coeffs_preset("nuttall", 24)
+    assert wt == 4 and a[:4] == [0.355768, 0.487396, 0.144232, 0.012604] and abs(sum(a) - 1.0) < 1e-12
+    assert aa == B.coeffs_from_float(4, 24, a) and aa[4:] == [0, 0, 0]
+    wt, a, aa = B.coeffs_preset("blackman-nuttall", 24)
+    assert wt == 4 and a[:4] == [0.3635819, 0.4891775, 0.1365995, 0.0106411]
+    for name in ("flat-top-1", "flat-top-2"):
+        wt, a, aa = B.coeffs_preset(name, 24)
+        assert wt == 5 and a[5:] == [0.0, 0.0]
+        assert abs(sum(a) - (1.1695 if name == "flat-top-1" else 1.0)) < 1e-8          # set (1) is not normalised upstream: peak 1.1695
+        assert aa == [int(round(v * ((1 << 22) - 1))) for v in a]             # s = 2 for 5 terms: win_function.cpp:312-316
+    wt, a, aa = B.coeffs_preset("bh7-readme", 32)
+    assert wt == 7 and a[0] == 0.27105140069342 and a[6] == 0.00001388721735 and abs(sum(a[0::2]) - sum(a[1::2])) < 1e-7   # w[0] ~ 0
+    wt, a, _ = B.coeffs_preset("blackman", 16)
+    assert wt == 3 and a[:3] == [0.42, 0.5, 0.08]
+    import pytest
+    with pytest.raises(B.BhwError):
+        B.coeffs_preset(99, 16)
+
+
+def test_describe_plan_names_the_run_length_kernel():
+    """Configurations that drop phase bits (z_shr > 0) run k_runlength_window behind the table build for whole periods; the plan
+    line -- what a profiler shows, what bench.py labels its kernels with -- must say so (round-2 advisor finding)."""
+    from blackman_harris_win_amd import binding as B
+    p = B.make_params(7, 26, 16, model=B.MODEL_CPP)
+    assert "k_runlength_window<7,1,true>" in B.describe_plan(p, 0, 1 << 26)
+    p = B.make_params(4, 24, 18, model=B.MODEL_VHDL, combine=B.COMBINE_VHDL)
+    assert "k_runlength_window<4,2,false>" in B.describe_plan(p, 0, 1 << 24)
+    p = B.make_params(7, 26, 32)                                  # no dropped bits: the tile kernel
+    assert "k_table_combine_tile<15,0," in B.describe_plan(p, 0, 1 << 26)
+    # AUTO keeps such configurations on the table strategy once they are long enough for the run-length kernel
+    p = B.make_params(4, 22, 8, model=B.MODEL_CPP)
+    assert B.describe_plan(p, 0, 1 << 22).startswith("table")
+    p = B.make_params(4, 12, 8, model=B.MODEL_CPP)
+    assert B.describe_plan(p, 0, 1 << 12).startswith("fused")
+
+
+def test_part_segments_and_generate_part_agree_on_applicability():
+    """Both part entry points refuse a configuration no part kernel covers (VHDL model, W = 32, PRECISION 3 below 2^22)."""
+    import ctypes
+    import pytest
+    from blackman_harris_win_amd import binding as B
+    p = B.make_params(7, 16, 32, model=B.MODEL_VHDL, precision=3)
+    with pytest.raises(B.BhwError) as e:
+        B.part_segments(p, 0, 2)
+    assert e.value.code == -2
+    assert B.lib().bhw_generate_part_device(ctypes.byref(p), 0, None, 0, 2, ctypes.c_void_p(16), None) == -2
+    assert len(B.part_segments(B.make_params(7, 16, 32, model=B.MODEL_VHDL, precision=1), 0, 2)) >= 1

@@ -17,7 +17,7 @@ PKG = os.path.join(ROOT, "blackman_harris_win_amd")
 def exe(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("cpp") / "host_mirror")
     subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
-                    os.path.join(ROOT, "tests", "cpp", "host_mirror.cpp"), "-o", out,
+                    os.path.join(ROOT, "host", "host_mirror.cpp"), "-o", out,
                     "-L" + PKG, "-lbhw", "-Wl,-rpath," + PKG], check=True)
     return out
 

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+UNOWNED = -(1 << 40)          # outside the int32 range: coefficients may be negative (caller-scaled weights, Hann at 10/24)
 
 
 def _free_port():
@@ -40,7 +41,7 @@ def _worker(rank, world, port, outdir):
     for win, pw, w in ((7, 22, 32), (4, 16, 24)):
         bp = B.make_params(win, pw, w)
         po = O.from_bhw(bp)
-        window = np.full(1 << pw, -1, np.int64)
+        window = np.full(1 << pw, UNOWNED, np.int64)
         for n0s, cnt in B.part_segments(bp, rank, world):
             window[n0s:n0s + cnt] = O.generate_mt(po, n0s, cnt, threads=2)
         np.save(os.path.join(outdir, f"part_{win}_{pw}_{rank}.npy"), window)
@@ -80,15 +81,52 @@ def test_two_rank_gloo(tmp_path):
     # the two ranks' interleaved parts tile the window: every coefficient owned (seam overlaps agree), values exact
     for win, pw, w in ((7, 22, 32), (4, 16, 24)):
         a, b = (np.load(tmp_path / f"part_{win}_{pw}_{r}.npy") for r in (0, 1))
-        both = (a >= 0) & (b >= 0)
-        assert ((a >= 0) | (b >= 0)).all() and both.sum() < (1 << pw) // 100
+        both = (a != UNOWNED) & (b != UNOWNED)
+        assert ((a != UNOWNED) | (b != UNOWNED)).all() and both.sum() < (1 << pw) // 100
         assert np.array_equal(a[both], b[both])
-        full = np.where(a >= 0, a, b).astype(np.int32)
+        full = np.where(a != UNOWNED, a, b).astype(np.int32)
         assert np.array_equal(full, O.generate_mt(O.oparams(win, pw, w), 0, 1 << pw))
 
 
-def test_bench_refuses_mismatched_world(monkeypatch):
+def _bench_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return env
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE (the form the driver uses at N = 1) starts its two ranks itself: the launch
+    path, process group, barrier / max-over-ranks protocol and the one JSON line from rank 0, over gloo without a GPU."""
+    import json
     import subprocess
-    env = dict(os.environ, WORLD_SIZE="1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, env=env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--launch-check"],
+                       capture_output=True, env=_bench_env(), timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                       # rank 0 only
+    rec = json.loads(lines[0])
+    assert rec["launch_check"] and rec["n_gpus"] == 2 and rec["steps"] == 5
+    assert rec["ms_per_step"] >= 0.9 * 2 * 2.0                   # the slower rank's time (rank 1 sleeps 4 ms per step)
+    assert rec["shard_of_last_rank"] == [1 << 26, 1 << 26]
+
+
+def test_bench_refuses_mismatched_world():
+    """Under a launcher that set WORLD_SIZE the rank count must match --gpus (no second launch from inside a rank)."""
+    import subprocess
+    env = dict(_bench_env(), WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, env=env, timeout=300)
     assert r.returncode != 0 and b"WORLD_SIZE" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_strong_scaling_two_ranks_share_one_gpu():
+    """bench.py --gpus 2 --scaling strong end to end through its own launcher: one 2^26 window as two interleaved ownership parts,
+    both ranks on this box's one GPU over gloo (a rehearsal of the launch path, not a measurement), parity checked on every rank."""
+    import json
+    import subprocess
+    env = dict(_bench_env(), BHW_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scaling", "strong", "--backend", "gloo",
+                        "--steps", "5", "--warmup", "2", "--ramp-seconds", "0.2"], capture_output=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    rec = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["parity_spot_check"] is True
+    assert rec["value"] > 0

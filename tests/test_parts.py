@@ -265,3 +265,27 @@ def test_plan_of_contiguous_eighth_ranges_on_the_host():
     for q in (B.make_params(4, 26, 24), B.make_params(7, 20, 32), B.make_params(7, 26, 16, model=B.MODEL_CPP)):
         n = 1 << q.phi_width
         assert "image subset" not in B.describe_plan(q, 0, n >> 3, algo=B.ALGO_TABLE)
+
+
+@pytest.mark.gpu
+def test_gather_parts_assembles_the_window():
+    """bhw_gather_parts_device: three parts generated into three separate full-length buffers (stand-ins for three devices' buffers:
+    this box has one GPU, so the peer copies are device copies), gathered into one window == the oracle, and nothing but the owned
+    segments is copied."""
+    import torch
+    import blackman_harris_win_amd as bhw
+    p = bhw.make_params(7, 22, 32)
+    n = 1 << 22
+    G = 3
+    wins = [torch.full((n,), -7, dtype=torch.int32, device="cuda") for _ in range(G)]
+    for g in range(G):
+        bhw.generate_part(p, g, G, wins[g])
+    out = torch.full((n,), -9, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    bhw.gather_parts(p, wins, out)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), O.generate_mt(O.from_bhw(p), 0, n))
+    # in place: part 0 already lives in the destination
+    bhw.gather_parts(p, [wins[0], wins[1], wins[2]], wins[0])
+    torch.cuda.synchronize()
+    assert torch.equal(wins[0], out)
