@@ -178,6 +178,19 @@ __host__ __device__ constexpr int gather_order(int K, int b, int g)     // consu
     return K == 1 ? b * 2 + g : K == 2 ? 6 + b : K == 3 ? 9 + b * 2 + g : K == 4 ? 15 + b : K == 5 ? 18 + b * 2 + g : 24 + b;
 }
 
+// One nibble-table entry (one byte at offset boff) for harmonic K.  The byte offsets of a wave's lanes are K apart, and the
+// CU's address path spends ~16 cycles on a load whose lanes are not consecutive elements against ~4.7 on one whose are
+// (profiles/r02_ubench_vmem.txt).  For K = 2 the entry is the low byte of 16-bit element r, for K = 4 of 32-bit element r: the
+// same bytes fetched as a unit-stride short / dword load (the unpack reads bits 0..7 only; boff is a multiple of K and
+// boff + K <= E, so the wider load stays inside the table).
+template <int K>
+__device__ __forceinline__ uint32_t ld_nibble(const void *__restrict__ table, uint32_t boff)
+{
+    if constexpr (K == 2) return (uint32_t)ld_off<uint16_t>(table, boff);
+    else if constexpr (K == 4) return ld_off<uint32_t>(table, boff);
+    else return (uint32_t)ld_off<uint8_t>(table, boff);
+}
+
 // Lane r in [0, E/2) owns the eight coefficients n = r + h*E/2 + j*E (h = 0,1; j = 0..3).  For even k the
 // two h-images share one gather (k*E/2 is a whole number of quadrants); for odd k the second image reads
 // entry t + E/2, another dense span of the same tile.
@@ -246,7 +259,7 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
                     if constexpr (FMT == 2 || FMT == 3) {                                               \
                         const uint32_t rg = rr[b] + (uint32_t)g * H;                                     \
                         const uint32_t boff = resid_offset<FMT, K>(rg, (uint32_t)K * rg, cls[b], lq, emask); \
-                        land[gather_order(K, b, g)] = FMT == 3 ? (uint32_t)ld_off<uint8_t>(table, boff) : (uint32_t)ld_off<uint16_t>(table, boff); \
+                        land[gather_order(K, b, g)] = FMT == 3 ? ld_nibble<K>(table, boff) : (uint32_t)ld_off<uint16_t>(table, boff); \
                     }                                                                                    \
                 }                                                                                        \
             }                                                                                            \
@@ -337,7 +350,7 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
                     if constexpr (kPrefetch && LDS) e = land[gather_order(K, b, g)];                     \
                     else {                                                                               \
                         const uint32_t boff = resid_offset<FMT, K>(rg, theta, cls[b], lq, emask_v);     \
-                        e = FMT == 3 ? (uint32_t)ld_off<uint8_t>(table, boff) : (uint32_t)ld_off<uint16_t>(table, boff); \
+                        e = FMT == 3 ? ld_nibble<K>(table, boff) : (uint32_t)ld_off<uint16_t>(table, boff); \
                     }                                                                                    \
                     cs[b][g] = resid_value<FMT, LDS>(cfg, theta, emask_v, rk, lrec, bias, e);            \
                 } else if constexpr (NB > 1 && (K & 1)) cs[b][g] = tab_load_class<FMT>(cfg, table, theta & emask_v, cls[b]); \
