@@ -441,24 +441,37 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
         if (W == 32u) store_all(std::true_type{});
         else store_all(std::false_type{});
     } else {
-        // Fused apply (emit()): one run at a time, its eight x samples fetched together before they are used
+        // Fused apply (emit()): y = (x * w) >> shift.  The x samples of every run of this pass are requested together before the
+        // first product (harmonic-major: 24 unit-stride loads in flight per thread; fetched eight at a time, run by run, the pass
+        // waited three times for HBM: 0.208 -> ms in profiles/r03_*), and x and y address as scalar image base + 32-bit lane offset
+        // like the plain stores.
+        int32_t xv[NR][2][4];
 #pragma unroll
-        for (int b = B0; b < B1; ++b) {
-            int32_t xv[2][4];
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int j = 0; j < 4; ++j) {
+                uint64_t img_off = (uint64_t)h * H + (uint64_t)j * E;
+                asm volatile("" : "+s"(img_off));
+                const int32_t *ximg = win.apply_x + img_off;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) xv[h][j] = win.apply_x[(uint64_t)(rr[b] + (uint32_t)h * H + (uint32_t)j * E)];
-            // all eight in registers before the first store (otherwise each load is sunk next to its use: load, wait, store, eight times)
-            asm volatile("" : "+v"(xv[0][0]), "+v"(xv[0][1]), "+v"(xv[0][2]), "+v"(xv[0][3]),
-                              "+v"(xv[1][0]), "+v"(xv[1][1]), "+v"(xv[1][2]), "+v"(xv[1][3]));
+                for (int b = B0; b < B1; ++b) xv[b][h][j] = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(ximg) + (rr[b] << 2));
+            }
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+        for (int b = B0; b < B1; ++b)      // all of them in registers before the first store (otherwise each load is sunk next to its use)
+            asm volatile("" : "+v"(xv[b][0][0]), "+v"(xv[b][0][1]), "+v"(xv[b][0][2]), "+v"(xv[b][0][3]),
+                              "+v"(xv[b][1][0]), "+v"(xv[b][1][1]), "+v"(xv[b][1][2]), "+v"(xv[b][1][3]));
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    out[(uint64_t)(rr[b] + (uint32_t)h * H + (uint32_t)j * E)] =
-                        (int32_t)(((int64_t)xv[h][j] * (int64_t)final_value(b, h, j)) >> win.apply_shift);
-        }
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint64_t img_off = (uint64_t)h * H + (uint64_t)j * E;
+                asm volatile("" : "+s"(img_off));
+                int32_t *img = out + img_off;
+#pragma unroll
+                for (int b = B0; b < B1; ++b)
+                    *reinterpret_cast<int32_t *>(reinterpret_cast<char *>(img) + (rr[b] << 2)) =
+                        (int32_t)(((int64_t)xv[b][h][j] * (int64_t)final_value(b, h, j)) >> win.apply_shift);
+            }
     }
     };
     if constexpr (kRunMajor && NR == 3) {
@@ -714,7 +727,7 @@ int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c_in, 
     const dim3 grid(tile_count), block(kTileThreads);
     // one-instruction products (tile_harmonic FAST): HLS rule, 15-run tiles, every harmonic weight below 2^(W-3) in magnitude
     // (the built-in weights are: a_k <= 0.49 * 2^(W-1 or W-2)); caller-scaled weights beyond that take the 64-bit products
-    bool fast = mode != 2 && nb == 15 && c.dat_width >= 3;
+    bool fast = nb == 15 && c.dat_width >= 3;
     for (uint32_t k = 1; k < w.n_terms && fast; ++k) {
         const int64_t lim = (int64_t)1 << (c.dat_width - 3);
         fast = (int64_t)w.aa[k] < lim && (int64_t)w.aa[k] > -lim;       // (> : the kernel also multiplies by the negated pre-shifted weight)
@@ -733,7 +746,7 @@ int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c_in, 
     } while (0)
 #define BHW_LAUNCH_TILE_M(NB, M)                                                                                         \
     do {                                                                                                                 \
-        if (NB == 15 && M != 2 && fast) BHW_LAUNCH_TILE_MF(NB, M, (NB == 15 && M != 2));                                 \
+        if (NB == 15 && fast) BHW_LAUNCH_TILE_MF(NB, M, (NB == 15));                                                    \
         else                            BHW_LAUNCH_TILE_MF(NB, M, false);                                                \
     } while (0)
 #define BHW_LAUNCH_TILE(NB)                                                                                              \

@@ -430,6 +430,21 @@ __device__ __forceinline__ void tile_harmonic(const BhwCordicCfg &cfg, const int
             p1 = __mulhi(na, cs.y);
             p2 = __mulhi(na, cs.x);
         }
+    } else if constexpr (FAST && MODE == 2) {
+        // VHDL rule on the pre-shifted weight: q = (a * v) >> (W-2) is one v_mul_hi_i32, and the slice-and-round of
+        // bh_win_7term.vhd:353-402,  (P >> (W-1)) + ((P >> (W-2)) & 1) = (q >> 1) + (q & 1) = (q + 1) >> 1  (floor shifts): three
+        // instructions per candidate instead of the 64-bit product, two shifts, mask and add
+        auto round_half = [&](int32_t q) -> int32_t { return wrap32((q + 1) >> 1, W); };
+        p0 = round_half(__mulhi(a, cs.x));
+        p3 = round_half(__mulhi(a, cs.y));
+        if (cfg.ones_neg) {
+            p1 = round_half(__mulhi(a, ~cs.y));
+            p2 = round_half(__mulhi(a, ~cs.x));
+        } else {
+            const int32_t na = -a;                         // a * (-v) == (-a) * v (the callers keep |a| < 2^(W-3))
+            p1 = round_half(__mulhi(na, cs.y));
+            p2 = round_half(__mulhi(na, cs.x));
+        }
     } else if constexpr (MODE == 2) {
         const int32_t nc = cfg.ones_neg ? ~cs.x : -cs.x;
         const int32_t ns = cfg.ones_neg ? ~cs.y : -cs.y;

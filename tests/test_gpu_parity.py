@@ -312,6 +312,11 @@ def test_weights_at_the_edge_of_the_one_instruction_products(torch, w):
         want = O.generate_mt(O.from_bhw(p), 0, n)
         assert np.array_equal(gpu_generate(p, 0, n, B.ALGO_TABLE), want), aa
         assert np.array_equal(bhw.generate(p, 0, n, algo=B.ALGO_FUSED).cpu().numpy(), want), aa
+        # the VHDL cosine-sum takes the same one-instruction products in the tile kernel ((q + 1) >> 1 on q = mul_hi), with either
+        # quadrant negation (model cpp: ~v)
+        for model in (B.MODEL_HLS, B.MODEL_CPP):
+            pv = B.make_params(7, 22, w, aa=aa, combine=B.COMBINE_VHDL, model=model)
+            assert np.array_equal(gpu_generate(pv, 0, n, B.ALGO_TABLE), O.generate_mt(O.from_bhw(pv), 0, n)), (aa, model)
 
 
 def test_strategies_agree_on_random_whole_windows(torch):
