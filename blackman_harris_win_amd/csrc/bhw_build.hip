@@ -297,6 +297,49 @@ __device__ __forceinline__ void rot_narrow(uint32_t &x, uint32_t &y, int32_t &z,
     }
 }
 
+// The last ten narrow rotations before the hand-over, KA = KS - 10 .. KS - 1, as ONE statement: entry at rotation KA + e (e <= 0: from the
+// top; the group's split rotation usually lies one or two rotations into the block), no scalar guard and no hazard no-op
+// between the rotations (the compiler separates adjacent asm statements that end / begin with EXEC accesses by an s_nop).
+template <int KA>
+__device__ __forceinline__ void rot_narrow_block(uint32_t &x, uint32_t &y, int32_t &z, uint32_t &zacc, const uint32_t *lut, int e)
+{
+    uint32_t a, b;
+#define BHW_ROT_I(i)                                                                                                   \
+    #i ":\n\t"                                                                                                          \
+    "v_lshrrev_b32 %[a], %[k" #i "], %[y]\n\t"                                                                          \
+    "v_lshrrev_b32 %[b], %[k" #i "], %[x]\n\t"                                                                          \
+    "v_min_u32 %[za], %[za], %[z]\n\t"                                                                                  \
+    "v_cmpx_gt_i32 vcc, 0, %[z]\n\t"                                                                                    \
+    "v_add_u32 %[x], %[x], %[a]\n\t"                                                                                    \
+    "v_sub_u32 %[y], %[y], %[b]\n\t"                                                                                    \
+    "v_add_u32 %[z], %[z], %[l" #i "]\n\t"                                                                              \
+    "s_not_b64 exec, exec\n\t"                                                                                          \
+    "v_sub_u32 %[x], %[x], %[a]\n\t"                                                                                    \
+    "v_add_u32 %[y], %[y], %[b]\n\t"                                                                                    \
+    "v_sub_u32 %[z], %[z], %[l" #i "]\n\t"                                                                              \
+    "s_mov_b64 exec, -1\n"
+    asm volatile("s_cmp_lt_i32 %[e], 1\n\ts_cbranch_scc1 0f\n\t"
+                 "s_cmp_eq_u32 %[e], 1\n\ts_cbranch_scc1 1f\n\t"
+                 "s_cmp_eq_u32 %[e], 2\n\ts_cbranch_scc1 2f\n\t"
+                 "s_cmp_eq_u32 %[e], 3\n\ts_cbranch_scc1 3f\n\t"
+                 "s_cmp_eq_u32 %[e], 4\n\ts_cbranch_scc1 4f\n\t"
+                 "s_cmp_eq_u32 %[e], 5\n\ts_cbranch_scc1 5f\n\t"
+                 "s_cmp_eq_u32 %[e], 6\n\ts_cbranch_scc1 6f\n\t"
+                 "s_cmp_eq_u32 %[e], 7\n\ts_cbranch_scc1 7f\n\t"
+                 "s_cmp_eq_u32 %[e], 8\n\ts_cbranch_scc1 8f\n\t"
+                 "s_cmp_eq_u32 %[e], 9\n\ts_cbranch_scc1 9f\n\t"
+                 "s_branch 10f\n"
+                 BHW_ROT_I(0) BHW_ROT_I(1) BHW_ROT_I(2) BHW_ROT_I(3) BHW_ROT_I(4) BHW_ROT_I(5) BHW_ROT_I(6) BHW_ROT_I(7) BHW_ROT_I(8) BHW_ROT_I(9)
+                 "10:"
+                 : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [za] "+v"(zacc), [a] "=&v"(a), [b] "=&v"(b)
+                 : [e] "s"(e), [l0] "s"(lut[KA]), [l1] "s"(lut[KA + 1]), [l2] "s"(lut[KA + 2]), [l3] "s"(lut[KA + 3]), [l4] "s"(lut[KA + 4]),
+                   [l5] "s"(lut[KA + 5]), [l6] "s"(lut[KA + 6]), [l7] "s"(lut[KA + 7]), [l8] "s"(lut[KA + 8]), [l9] "s"(lut[KA + 9]),
+                   [k0] "n"(KA), [k1] "n"(KA + 1), [k2] "n"(KA + 2), [k3] "n"(KA + 3), [k4] "n"(KA + 4), [k5] "n"(KA + 5), [k6] "n"(KA + 6),
+                   [k7] "n"(KA + 7), [k8] "n"(KA + 8), [k9] "n"(KA + 9)
+                 : "vcc", "scc");
+#undef BHW_ROT_I
+}
+
 template <int NITER, int FMT>
 __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPlan plan, void *__restrict__ table)
 {
@@ -331,20 +374,25 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
             work_n = 1u;
         }
     }
-    // tail tables: D copied from its constant image (16 bytes per thread), the pattern of every z_KS from the ROM words
-    reinterpret_cast<int4 *>(tail_d)[threadIdx.x] = reinterpret_cast<const int4 *>(kTailD.v)[threadIdx.x];
+    // tail tables, by the fourth wave alone (the first three run the prefix and head chains below, and every workgroup starts
+    // with this serial phase): D copied from its constant image, the pattern of every z_KS from the ROM words
+    if (threadIdx.x >= 192u) {
+        const uint32_t t3 = threadIdx.x - 192u;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const uint32_t zi = threadIdx.x + (uint32_t)half * kBuildThreads;
-        int32_t z = (int32_t)zi - kTailZ;
-        uint32_t p = 0u;
+        for (int q = 0; q < 4; ++q) reinterpret_cast<int4 *>(tail_d)[t3 + 64u * q] = reinterpret_cast<const int4 *>(kTailD.v)[t3 + 64u * q];
 #pragma unroll
-        for (int j = 0; j < kMirrorTail; ++j) {
-            if (z < 0) { p |= 1u << j; z += (int32_t)plan.lut[KS + j]; } else z -= (int32_t)plan.lut[KS + j];
+        for (int q = 0; q < 2 * kTailZ / 64; ++q) {
+            const uint32_t zi = t3 + 64u * (uint32_t)q;
+            int32_t z = (int32_t)zi - kTailZ;
+            uint32_t p = 0u;
+#pragma unroll
+            for (int j = 0; j < kMirrorTail; ++j) {
+                if (z < 0) { p |= 1u << j; z += (int32_t)plan.lut[KS + j]; } else z -= (int32_t)plan.lut[KS + j];
+            }
+            tail_p[zi] = (uint8_t)p;
         }
-        tail_p[zi] = (uint8_t)p;
     }
-    __syncthreads();
+    // (no barrier here: the tail tables and lut_s are first read in phase 2, behind the two barriers below)
 
 
     // records {c, s, dc, ds} of the cells this workgroup stores into: w = 0 its own range, w = 1 the image range.  Heads
@@ -371,7 +419,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
             const int64_t cell = (t <= n_cell[w]) ? (int64_t)cell_lo[w] + t : (int64_t)cell_lo[w] - 1;
             if (cell >= 0 && cell < (int64_t)cells_total) {
                 int64_t x = plan.x0, y = plan.x0;
-                int32_t z = (int32_t)((((uint32_t)cell << d) << s) - lut_s[0]);
+                int32_t z = (int32_t)((((uint32_t)cell << d) << s) - plan.lut[0]);
 #pragma unroll
                 for (int r = 1; r < n_iter; ++r) rot_step(x, y, z, r, plan.lut[r]);
                 hc[w][t] = (int32_t)(x >> plan.out_shr);
@@ -386,7 +434,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
         const uint32_t g = group0 + threadIdx.x;
         const uint32_t u_first = g << 6;
         int64_t x = plan.x0, y = plan.x0;                                        // after rotation 0
-        int32_t zf = (int32_t)((u_first << s) - lut_s[0]);
+        int32_t zf = (int32_t)((u_first << s) - plan.lut[0]);
         const uint32_t span = 63u << s;                                          // z_last - z_first
         int k = 1;
         bool live = g < n_groups;
@@ -473,21 +521,19 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
             // ---- narrow state: 32-bit words, EXEC-masked add / sub, table tail ----
             uint32_t x = (uint32_t)gx[gi], y = (uint32_t)gy[gi];
             uint32_t zacc = ~0u;                                      // min over the rotations of (unsigned)z_k: 0 = a zero event
-            // entry at the group's split rotation k0 (17 or 18 at 2^26 / 32 bits): one scalar guard per rotation below kcap, the
-            // first eleven behind one test (a switch with fall-through is lowered to a flag machine that costs 10 us of the pass)
-#define BHW_NARROW(K) if constexpr (K < KS && K < kcap) { if (K >= k0) rot_narrow<K, true>(x, y, z, zacc, plan.lut[K]); }
-            if (k0 < 12) {
+            // entry at the group's split rotation k0 (17 or 18 at 2^26 / 32 bits): rotations below KA = KS - 10 behind one scalar guard
+            // each (rare: a group that splits that early), the last ten as one block entered at k0 (a switch with fall-through is
+            // lowered to a flag machine that costs 10 us of the pass)
+            constexpr int KA = KS - 10;
+            static_assert(KA >= 5 && KA < kcap && KS - KA == 10, "ten-rotation block");
+            if (k0 < KA) {
+#define BHW_NARROW(K) if constexpr (K < KA) { if (K >= k0) rot_narrow<K, true>(x, y, z, zacc, plan.lut[K]); }
                 BHW_NARROW(1) BHW_NARROW(2) BHW_NARROW(3) BHW_NARROW(4) BHW_NARROW(5) BHW_NARROW(6) BHW_NARROW(7) BHW_NARROW(8)
-                BHW_NARROW(9) BHW_NARROW(10) BHW_NARROW(11)
+                BHW_NARROW(9) BHW_NARROW(10) BHW_NARROW(11) BHW_NARROW(12) BHW_NARROW(13) BHW_NARROW(14) BHW_NARROW(15)
+#undef BHW_NARROW
             }
-            BHW_NARROW(12) BHW_NARROW(13) BHW_NARROW(14) BHW_NARROW(15) BHW_NARROW(16) BHW_NARROW(17) BHW_NARROW(18) BHW_NARROW(19)
-#undef BHW_NARROW
-#define BHW_NARROW(K) if constexpr (K < KS && K >= kcap) rot_narrow<K, true>(x, y, z, zacc, plan.lut[K]);
-            BHW_NARROW(15) BHW_NARROW(16) BHW_NARROW(17) BHW_NARROW(18) BHW_NARROW(19) BHW_NARROW(20) BHW_NARROW(21) BHW_NARROW(22)
-            BHW_NARROW(23) BHW_NARROW(24) BHW_NARROW(25)
-#undef BHW_NARROW
+            rot_narrow_block<KA>(x, y, z, zacc, plan.lut, k0 - KA);
             zmask = __builtin_amdgcn_ballot_w64(zacc == 0u);
-            static_assert(kPrefixMax == 20, "the switch covers the guarded rotations 1 .. kcap - 1 <= 19");
             static_assert(KS <= 26, "unrolled to rotation 25");
             constexpr uint32_t lowm = (1u << KS) - 1u;
             const uint32_t zi = (uint32_t)(z + kTailZ);              // own pattern at zi, the image's (z -> -z) at 2 kTailZ - zi
