@@ -78,7 +78,9 @@ def compile_units(objdir, flags=(), jobs=None, only=None):
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
-    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+    # --offload-compress: the gfx950 code objects are stored zstd-compressed in the fat binary (the HIP runtime inflates them at
+    # load time): 4.7 MB -> ~1.5 MB of shared library for the same kernels
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "--offload-compress",
             "-Rpass-analysis=kernel-resource-usage"] + list(flags)
     jobsl = []
     for unit in ("bhw_api.cpp",) + KERNEL_UNITS:

@@ -879,7 +879,7 @@ int bhw_dbg_check_table_format(const bhw_params *p, int device, void *stream, ui
     if (validate(p) || !ws || !flag_out || dlog < 6 || (dlog > 9 && (dlog < 16u + 7u || dlog > 16u + 9u))) return BHW_ERR_BADARG;
     BhwCordicCfg c;
     resolve_cordic(p, c);
-    if (c.z_shr != 0 || c.n_iter < 21 || c.dat_width + c.out_shr > 34 || table_entries(c) < (1ull << 12)) return BHW_ERR_UNSUPPORTED;
+    if (c.z_shr != 0 || c.n_iter < 21 || c.dat_width + c.out_shr > 34 || table_entries(c) < (1ull << 20)) return BHW_ERR_UNSUPPORTED;   // packed tables exist for tiled windows (PW >= 22) only
     DeviceGuard guard(device);
     const uint64_t E = table_entries(c);
     c.tab_split = 1u;

@@ -771,7 +771,7 @@ int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c_in, int32_t *d_ta
         }
 #define BHW_LAUNCH_BUILD(N, F) BHW_LAUNCH((k_table_build_shared<N, F>), grid, block, 0, st, plan, (void *)d_table)
 #define BHW_CASE(N) case N: BHW_LAUNCH_BUILD(N, 0); break;
-#define BHW_CASE_T(N) case N: if (fmt == 0) BHW_LAUNCH_BUILD(N, 0); else if (fmt == 1) BHW_LAUNCH_BUILD(N, 1); else if (fmt == 2) BHW_LAUNCH_BUILD(N, 2); else BHW_LAUNCH_BUILD(N, 3); break;
+#define BHW_CASE_T(N) case N: if (fmt == 0) BHW_LAUNCH_BUILD(N, 0); else if (fmt == 1) BHW_LAUNCH_BUILD(N, 1); else return (int)hipErrorInvalidValue; break;   /* residual / nibble tables: the mirror kernel above (tables of 2^20 entries and more, the only ones that use them) */
         switch (c.n_iter) {
             BHW_CASE(7) BHW_CASE(8) BHW_CASE(9) BHW_CASE(10) BHW_CASE(11) BHW_CASE(12) BHW_CASE(13) BHW_CASE(14)
             BHW_CASE(15) BHW_CASE(16) BHW_CASE(17) BHW_CASE(18) BHW_CASE(19) BHW_CASE(20)

@@ -445,33 +445,57 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
         // first product (harmonic-major: 24 unit-stride loads in flight per thread; fetched eight at a time, run by run, the pass
         // waited three times for HBM: 0.208 -> ms in profiles/r03_*), and x and y address as scalar image base + 32-bit lane offset
         // like the plain stores.
-        int32_t xv[NR][2][4];
+        auto apply_runs = [&](const int b0, const int b1) {
+            int32_t xv[NR][2][4];
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                uint64_t img_off = (uint64_t)h * H + (uint64_t)j * E;
-                asm volatile("" : "+s"(img_off));
-                const int32_t *ximg = win.apply_x + img_off;
+                for (int j = 0; j < 4; ++j) {
+                    uint64_t img_off = (uint64_t)h * H + (uint64_t)j * E;
+                    asm volatile("" : "+s"(img_off));
+                    const int32_t *ximg = win.apply_x + img_off;
 #pragma unroll
-                for (int b = B0; b < B1; ++b) xv[b][h][j] = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(ximg) + (rr[b] << 2));
+                    for (int b = 0; b < NR; ++b)
+                        if (b >= b0 && b < b1) xv[b][h][j] = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(ximg) + (rr[b] << 2));
+                }
+#pragma unroll
+            for (int b = 0; b < NR; ++b)     // all of them in registers before the first store (otherwise each load is sunk next to its use)
+                if (b >= b0 && b < b1)
+                    asm volatile("" : "+v"(xv[b][0][0]), "+v"(xv[b][0][1]), "+v"(xv[b][0][2]), "+v"(xv[b][0][3]),
+                                      "+v"(xv[b][1][0]), "+v"(xv[b][1][1]), "+v"(xv[b][1][2]), "+v"(xv[b][1][3]));
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint64_t img_off = (uint64_t)h * H + (uint64_t)j * E;
+                    asm volatile("" : "+s"(img_off));
+                    int32_t *img = out + img_off;
+#pragma unroll
+                    for (int b = 0; b < NR; ++b)
+                        if (b >= b0 && b < b1)
+                            *reinterpret_cast<int32_t *>(reinterpret_cast<char *>(img) + (rr[b] << 2)) =
+                                (int32_t)(((int64_t)xv[b][h][j] * (int64_t)final_value(b, h, j)) >> win.apply_shift);
+                }
+        };
+        if constexpr (NB >= 15) apply_runs(B0, B1);                  // 64 registers hold the 24 sums and the 24 samples
+        else {                                                       // one-part tiles (n_terms <= 5) carry more state: run by run
+#pragma unroll
+            for (int b = B0; b < B1; ++b) {
+                int32_t xv[2][4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xv[h][j] = win.apply_x[(uint64_t)(rr[b] + (uint32_t)h * H + (uint32_t)j * E)];
+                asm volatile("" : "+v"(xv[0][0]), "+v"(xv[0][1]), "+v"(xv[0][2]), "+v"(xv[0][3]),
+                                  "+v"(xv[1][0]), "+v"(xv[1][1]), "+v"(xv[1][2]), "+v"(xv[1][3]));
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        out[(uint64_t)(rr[b] + (uint32_t)h * H + (uint32_t)j * E)] =
+                            (int32_t)(((int64_t)xv[h][j] * (int64_t)final_value(b, h, j)) >> win.apply_shift);
             }
-#pragma unroll
-        for (int b = B0; b < B1; ++b)      // all of them in registers before the first store (otherwise each load is sunk next to its use)
-            asm volatile("" : "+v"(xv[b][0][0]), "+v"(xv[b][0][1]), "+v"(xv[b][0][2]), "+v"(xv[b][0][3]),
-                              "+v"(xv[b][1][0]), "+v"(xv[b][1][1]), "+v"(xv[b][1][2]), "+v"(xv[b][1][3]));
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                uint64_t img_off = (uint64_t)h * H + (uint64_t)j * E;
-                asm volatile("" : "+s"(img_off));
-                int32_t *img = out + img_off;
-#pragma unroll
-                for (int b = B0; b < B1; ++b)
-                    *reinterpret_cast<int32_t *>(reinterpret_cast<char *>(img) + (rr[b] << 2)) =
-                        (int32_t)(((int64_t)xv[b][h][j] * (int64_t)final_value(b, h, j)) >> win.apply_shift);
-            }
+        }
     }
     };
     if constexpr (kRunMajor && NR == 3) {

@@ -318,15 +318,17 @@ int bhwk_taylor_window_fold(const BhwLaunch &l, const BhwTaylorCfg &t, const Bhw
     if (blocks > 4096u) blocks = 4096u;
     const dim3 grid(blocks);
     hipStream_t st = (hipStream_t)l.stream;
-#define BHW_TAYLOR_FOLD(ARITH, COMBINE, NT)                                                                         \
-    do {                                                                                                            \
-        if (fast) BHW_LAUNCH((k_taylor_window_fold<ARITH, COMBINE, NT, true>), grid, dim3(kBlock), 0, st, t, w, d_out);  \
-        else      BHW_LAUNCH((k_taylor_window_fold<(ARITH == 2 ? 0 : ARITH), COMBINE, NT, false>), grid, dim3(kBlock), 0, st, t, w, d_out); \
-    } while (0)
+#define BHW_TAYLOR_FOLD(ARITH, COMBINE, NT) BHW_LAUNCH((k_taylor_window_fold<ARITH, COMBINE, NT, true>), grid, dim3(kBlock), 0, st, t, w, d_out)
     const bool vhdl = w.combine == BHW_COMBINE_VHDL;
     // every generator in use (PHASE_WIDTH - v, v <= vmax) on the 1st-order-correction path, ROM in LDS
     const int vmax = w.n_terms > 4 ? 2 : w.n_terms > 2 ? 1 : 0;
     const bool fast = (1u << t.lut_size) <= (uint32_t)kTaylorRomLds && (int)t.phi_width - vmax - (int)t.lut_size > 2;
+    if (!fast) {
+        // a quarter-wave ROM beyond LDS (LUT_SIZE > 12) or a generator without the correction stage (PHASE_WIDTH - LUT_SIZE <= 3):
+        // the general one-lane-per-coefficient kernel over the period (the fold kernel is instantiated in its usual form only)
+        BHW_LAUNCH(k_taylor_window, dim3(grid_for(4ull * E)), dim3(kBlock), 0, st, t, w, (uint64_t)0, (uint64_t)(4ull * E), d_out);
+        return finish(hipSuccess);
+    }
     // 32-bit arithmetic: int16-sized operands (W <= 16), or the wide rounding variant with its shift inside one mul_hi
     const int arith = narrow ? 1 : (fast && t.dat_width >= 19 && t.xshift >= 24 && t.xshift <= 32) ? 2 : 0;
 #define BHW_TAYLOR_FOLD_NT(NT)                                                                                      \
