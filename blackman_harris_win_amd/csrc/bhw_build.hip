@@ -613,15 +613,16 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
             store_entry(idx_i - idx, c2, s2, rec2, um & fmask);
         }
     }
-    // ---- the deferred images: one lane each, the whole chain ----
+    // ---- the deferred images: one lane each.  The chain is unrolled on the scalar ROM words (the rolled loop on the LDS copy kept
+    // every workgroup 1.5 us longer at the end of the kernel, where nothing else is left to overlap it) ----
     __syncthreads();
     const uint32_t n_work = work_n < kWorkMax ? work_n : kWorkMax;
     for (uint32_t i = threadIdx.x; i < n_work; i += kBuildThreads) {
         const uint32_t um = E - work_u[i];
         int64_t xf = plan.x0, yf = plan.x0;
-        int32_t zf = (int32_t)((um << s) - lut_s[0]);
-#pragma unroll 1
-        for (int r = 1; r < n_iter; ++r) rot_step(xf, yf, zf, r, lut_s[r]);
+        int32_t zf = (int32_t)((um << s) - plan.lut[0]);
+#pragma unroll
+        for (int r = 1; r < n_iter; ++r) rot_step(xf, yf, zf, r, plan.lut[r]);     // (restarting from the group's parked state, per-lane start rotation: +0.3 us)
         store_entry(tab_index(um, plan.log2_entries, plan.tab_split), (int32_t)(xf >> plan.out_shr), (int32_t)(yf >> plan.out_shr), record_of(1, um >> d), um & fmask);
     }
 }
