@@ -271,17 +271,28 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
     if constexpr (kLdsRec) {
         const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const uint32_t d = fmt_cell_log(cfg.tab_dlog);
+        // Does a run wrap around the ring, or a harmonic's entries around the table?  One lane per test (lane 9 b + si: set si of run b;
+        // lanes 27 .. 29: the runs themselves) and one vote, instead of 30 scalar compare / select / or chains per wave: the CU's one
+        // scalar unit serves four SIMDs, and this kernel issues as many scalar as vector cycles (profiles/r03_pmc_summary.json).
+        {
+            static_assert(NR == 3 && kRecSets == 9, "lane -> (run, set) below");
+            const uint32_t li = threadIdx.x & 63u;
+            const uint32_t bq = li < 27u ? li / 9u : li - 27u, si = li - 9u * bq;       // (si meaningful for li < 27)
+            const uint32_t st = bq == 0u ? starts[0] : bq == 1u ? starts[1] : starts[2];
+            const uint32_t K = (uint32_t)(0x655433211ull >> (4u * (si < 9u ? si : 0u))) & 15u;   // rec_set_K(si): 1 1 2 3 3 4 5 5 6
+            const uint32_t g = (0x92u >> (si < 9u ? si : 0u)) & 1u;                               // rec_set_g(si): sets 1, 4, 7
+            const uint32_t u0 = (K * (st + g * H)) & emask;
+            const bool w = li < 27u ? u0 + K * (uint32_t)(kLanes - 1) > emask : li < 30u ? st + (uint32_t)kLanes > H : false;
+            wraps = __builtin_amdgcn_ballot_w64(w) != 0ull;
+        }
 #pragma unroll
         for (int b = 0; b < NR; ++b) {
-            wraps |= starts[b] + (uint32_t)kLanes > H;
             qpack[b] = 0u;
 #pragma unroll
             for (int si = 0; si < kRecSets; ++si) {
                 const uint32_t K = rec_set_K(si);
                 const uint32_t th0 = K * (starts[b] + (uint32_t)rec_set_g(si) * H);
-                const uint32_t u0 = th0 & emask;
                 qpack[b] |= ((th0 >> lq) & 3u) << (2 * si);
-                wraps |= u0 + K * (uint32_t)(kLanes - 1) > emask;
                 rbias[si][b] = (((wave * NR + b) * kRecPerRun + (uint32_t)rec_set_base(si)) << 4) - ((th0 >> d) << 4);   // cell of the unmasked angle (resid_value)
             }
         }
