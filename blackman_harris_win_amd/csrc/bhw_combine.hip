@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kBlock) void k_table_combine_fold_t(BhwCordicCfg cf
     acc_t acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        if constexpr (MODE == 2) acc[j] = Sum32{win.aa[0] >> 2, win.aa[0] & 3};
+        if constexpr (MODE == 2) acc[j] = sum32_first(win.aa[0]);
         else acc[j] = win.aa[0];
     }
     int32_t sv[4];
@@ -201,7 +201,10 @@ template <int NB, int MODE, int FMT, bool FAST = false, bool MASKED = false>
 __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 4 : 8))) void k_table_combine_tile(BhwCordicCfg cfg, BhwWinCfg win, BhwTilePlan tp,
                                                                       const void *__restrict__ table, int32_t *__restrict__ out)
 {
-    using acc_t = typename std::conditional<MODE == 2, Sum32, int32_t>::type;
+    // VHDL rule: the W+2-bit sum as two words (Sum32) in general; FAST instances are launched only when the sum of the |a_k| stays
+    // below 2^31 (every term b_k is at most |a_k| + 1 in magnitude), so the exact sum is one 32-bit word
+    constexpr bool kWideSum = MODE == 2 && !FAST;
+    using acc_t = typename std::conditional<kWideSum, Sum32, int32_t>::type;
     const uint32_t lq = cfg.phi_width - 2;
     const uint32_t E = 1u << lq, emask = E - 1u, H = E >> 1, hmask = H - 1u;
     const uint32_t W = cfg.dat_width;
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
     uint32_t cls[NR];                                                // residue class of r in the split layout (odd harmonics)
 #pragma unroll
     for (int b = 0; b < NR; ++b) cls[b] = split_class<FMT>(rr[b], lq);
-    constexpr bool kRunMajor = NB >= 15 && (MODE == 2 || !FAST);   // also the 64-bit-product form (caller-scaled weights): no registers to spare otherwise
+    constexpr bool kRunMajor = NB >= 15 && !FAST;   // also the 64-bit-product form (caller-scaled weights): no registers to spare otherwise
     constexpr bool kPrefetch = kRunMajor && kLdsRec && NR == 3;
     uint32_t land[kPrefetch ? 27 : 1];                               // residual words, one per gather (gather_order)
     // MASKED: which half-period images (h = 0: even image numbers, h = 1: odd) this launch wants at all
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if constexpr (MODE == 2) acc[b][h][j] = Sum32{win.aa[0] >> 2, win.aa[0] & 3};
+                    if constexpr (kWideSum) acc[b][h][j] = sum32_first(win.aa[0]);
                     else acc[b][h][j] = win.aa[0];
                 }
     };
@@ -422,7 +425,8 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
     };
 
     auto final_value = [&](int b, int h, int j) -> int32_t {
-        if constexpr (MODE == 2) return w32_final<BHW_COMBINE_VHDL>(acc[b][h][j], W, win.n_terms);
+        if constexpr (kWideSum) return w32_final<BHW_COMBINE_VHDL>(acc[b][h][j], W, win.n_terms);
+        else if constexpr (MODE == 2) return w32_final_exact(acc[b][h][j], W, win.n_terms);
         else return (int32_t)((uint32_t)acc[b][h][j] << (32u - W)) >> (32u - W);   // (win_t)(...) wrap to W bits
     };
     auto store_runs = [&](auto run_tag) {
@@ -766,6 +770,12 @@ int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c_in, 
     for (uint32_t k = 1; k < w.n_terms && fast; ++k) {
         const int64_t lim = (int64_t)1 << (c.dat_width - 3);
         fast = (int64_t)w.aa[k] < lim && (int64_t)w.aa[k] > -lim;       // (> : the kernel also multiplies by the negated pre-shifted weight)
+    }
+    if (mode == 2 && fast) {
+        // VHDL rule, one-word sums: |sum of the terms| <= sum of (|a_k| + 1) must stay below 2^31 (the built-in weights: < 2^(W-1))
+        int64_t bound = 0;
+        for (uint32_t k = 0; k < w.n_terms; ++k) bound += (w.aa[k] < 0 ? -(int64_t)w.aa[k] : (int64_t)w.aa[k]) + 1;
+        fast = bound < ((int64_t)1 << 31);
     }
 #define BHW_LAUNCH_TILE_MFK(NB, M, F, K)                                                                                 \
     do {                                                                                                                 \

@@ -365,13 +365,17 @@ __device__ __forceinline__ int32_t wrap32(int32_t v, uint32_t bits)
 
 
 // W-bit sums of the cosine-sum rules in 32-bit registers.  HLS rule: everything modulo 2^32, wrapped to W bits at the end.
-// VHDL rule: the sum needs W+2 bits, so it is carried as S = 4*hi + lo (hi modulo 2^32, lo a small exact integer):
+// VHDL rule: the sum S of the terms b_k needs W+2 bits, so two 32-bit words are carried (both modulo 2^32):
 //   b_k = wrap_W((P >> (W-1)) + ((P >> (W-2)) & 1))   == the slice-and-round of bh_win_7term.vhd:353-402 on the 2W-bit product P
-//   S>>2 = hi + (lo>>2),  (S>>1)&1 = (lo>>1)&1,  S>>1 = 2*hi + (lo>>1),  S&1 = lo&1
+//   hi  = sum of +/- (b_k >> 2),   sum = sum of +/- b_k = S mod 2^32
+// and lo = sum - 4*hi = the sum of the +/- (b_k & 3), a small integer (|lo| <= 3 * 7) that 32-bit arithmetic returns exactly:
+//   S = 4*hi + lo,  S>>2 = hi + (lo>>2),  (S>>1)&1 = (lo>>1)&1,  S>>1 = 2*hi + (lo>>1),  S&1 = lo&1
+// (one shift and two adds per term; carrying lo itself costs a mask more per term)
 struct Sum32 {
-    int32_t hi, lo;
-    __device__ __forceinline__ Sum32 &operator+=(const Sum32 &o) { hi += o.hi; lo += o.lo; return *this; }
+    int32_t hi, sum;
+    __device__ __forceinline__ Sum32 &operator+=(const Sum32 &o) { hi += o.hi; sum += o.sum; return *this; }
 };
+__device__ __forceinline__ Sum32 sum32_first(int32_t a0) { return Sum32{a0 >> 2, a0}; }      // the a_0 term of the VHDL rule
 
 __device__ __forceinline__ int32_t acc_value(int32_t v) { return v; }
 __device__ __forceinline__ int32_t acc_value(const Sum32 &v) { return v.hi; }
@@ -385,8 +389,8 @@ __device__ __forceinline__ void w32_term(Sum32 &acc, int32_t a, int32_t v, uint3
         acc.hi += (k & 1u) ? -m : m;
     } else {
         const int32_t b = wrap32((int32_t)(P >> (W - 1)) + (int32_t)(((uint32_t)P >> (W - 2)) & 1u), W);
-        if (k & 1u) { acc.hi -= b >> 2; acc.lo -= b & 3; }
-        else        { acc.hi += b >> 2; acc.lo += b & 3; }
+        if (k & 1u) { acc.hi -= b >> 2; acc.sum -= b; }
+        else        { acc.hi += b >> 2; acc.sum += b; }
     }
 }
 
@@ -394,8 +398,16 @@ template <uint32_t COMBINE>
 __device__ __forceinline__ int32_t w32_final(const Sum32 &acc, uint32_t W, uint32_t n_terms)
 {
     if constexpr (COMBINE == BHW_COMBINE_HLS) return wrap32(acc.hi, W);
-    else if (n_terms == 2) return wrap32(2 * acc.hi + (acc.lo >> 1) + (acc.lo & 1), W);          // hamming_win.vhd:214-228
-    else return wrap32(acc.hi + (acc.lo >> 2) + ((acc.lo >> 1) & 1), W);                         // bh_win_7term.vhd:409-435
+    const int32_t lo = (int32_t)((uint32_t)acc.sum - 4u * (uint32_t)acc.hi);
+    if (n_terms == 2) return wrap32(2 * acc.hi + (lo >> 1) + (lo & 1), W);                        // hamming_win.vhd:214-228
+    return wrap32(acc.hi + (lo >> 2) + ((lo >> 1) & 1), W);                                       // bh_win_7term.vhd:409-435
+}
+
+// VHDL rule when the exact sum S of the terms fits one 32-bit word (the caller checks the weights): the same roundings on S itself
+__device__ __forceinline__ int32_t w32_final_exact(int32_t S, uint32_t W, uint32_t n_terms)
+{
+    const uint32_t sh = n_terms == 2 ? 1u : 2u;                  // hamming_win.vhd:214-228: (S >> 1) + (S & 1); bh_win_7term.vhd:409-435: (S >> 2) + ((S >> 1) & 1)
+    return wrap32((S >> sh) + (int32_t)(((uint32_t)S >> (sh - 1u)) & 1u), W);
 }
 
 // MODE 0: HLS cosine-sum, two's-complement quadrant map, sums kept modulo 2^32 (exact: the result is
@@ -432,19 +444,18 @@ __device__ __forceinline__ void tile_harmonic(const BhwCordicCfg &cfg, const int
         }
     } else if constexpr (FAST && MODE == 2) {
         // VHDL rule on the pre-shifted weight: q = (a * v) >> (W-2) is one v_mul_hi_i32, and the slice-and-round of
-        // bh_win_7term.vhd:353-402,  (P >> (W-1)) + ((P >> (W-2)) & 1) = (q >> 1) + (q & 1) = (q + 1) >> 1  (floor shifts): three
-        // instructions per candidate instead of the 64-bit product, two shifts, mask and add
-        auto round_half = [&](int32_t q) -> int32_t { return wrap32((q + 1) >> 1, W); };
+        // bh_win_7term.vhd:353-402,  (P >> (W-1)) + ((P >> (W-2)) & 1) = (q >> 1) + (q & 1) = (q + 1) >> 1  (floor shifts), wrapped
+        // to W bits = bits 1 .. W of q + 1 sign-extended: v_mul_hi_i32, v_add, v_bfe_i32 per candidate (at W = 32 the field is
+        // bits 1 .. 31, i.e. the arithmetic shift) instead of the 64-bit product, two shifts, mask, add and the two wrap shifts
+        const uint32_t wb = W < 31u ? W : 31u;
+        auto round_half = [&](int32_t q) -> int32_t { return __builtin_amdgcn_sbfe(q + 1, 1u, wb); };
         p0 = round_half(__mulhi(a, cs.x));
         p3 = round_half(__mulhi(a, cs.y));
-        if (cfg.ones_neg) {
-            p1 = round_half(__mulhi(a, ~cs.y));
-            p2 = round_half(__mulhi(a, ~cs.x));
-        } else {
-            const int32_t na = -a;                         // a * (-v) == (-a) * v (the callers keep |a| < 2^(W-3))
-            p1 = round_half(__mulhi(na, cs.y));
-            p2 = round_half(__mulhi(na, cs.x));
-        }
+        // either quadrant map without a branch per gather: two's complement a * (-v) == (-a) * v (the callers keep |a| < 2^(W-3)),
+        // one's complement a * ~v; the mask and the weight are scalars
+        const int32_t flip = cfg.ones_neg ? -1 : 0, na = cfg.ones_neg ? a : -a;
+        p1 = round_half(__mulhi(na, cs.y ^ flip));
+        p2 = round_half(__mulhi(na, cs.x ^ flip));
     } else if constexpr (MODE == 2) {
         const int32_t nc = cfg.ones_neg ? ~cs.x : -cs.x;
         const int32_t ns = cfg.ones_neg ? ~cs.y : -cs.y;
@@ -554,18 +565,37 @@ __device__ __forceinline__ void tile_accumulate_uniform(uint32_t q, const int32_
 #undef BHW_UNI4
     }
 }
-// VHDL rule: the W+2-bit sums are carried as 4*hi + lo (Sum32), a term b adds b >> 2 to hi and b & 3 to lo -- the two halves of
-// the four candidates once, then the same scalar-branched accumulate for each half.
+// VHDL rule: the W+2-bit sums are carried as (hi, sum) (Sum32): a term b adds b >> 2 to hi and b itself to sum -- the high parts of
+// the four candidates once, then the same scalar-branched accumulate for each word.
 template <int K, int OFF, int QBASE, int QBITS>
 __device__ __forceinline__ void tile_accumulate_uniform(uint32_t q, const int32_t (&sv)[4], Sum32 (&acc)[4])
 {
-    int32_t svh[4], svl[4], h[4], l[4];
+    int32_t svh[4], h[4], l[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { svh[i] = sv[i] >> 2; svl[i] = sv[i] & 3; h[i] = acc[i].hi; l[i] = acc[i].lo; }
-    tile_accumulate_uniform<K, OFF, QBASE, QBITS>(q, svh, h);
-    tile_accumulate_uniform<K, OFF, QBASE, QBITS>(q, svl, l);
+    for (int i = 0; i < 4; ++i) { svh[i] = sv[i] >> 2; h[i] = acc[i].hi; l[i] = acc[i].sum; }
+    if constexpr (QBITS == 1) {
+        // both words behind ONE scalar compare-and-branch (the scalar unit is what this kernel runs short of)
+        auto S = [&](int j, int Q) -> int32_t { return sv[(j * K + OFF + Q) & 3]; };
+        auto H = [&](int j, int Q) -> int32_t { return svh[(j * K + OFF + Q) & 3]; };
+#define BHW_UNI2W(OP)                                                                                                  \
+        asm("s_cmp_eq_u32 %24, %25\n\ts_cbranch_scc0 1f\n\t"                                                          \
+            OP " %0, %0, %8\n\t" OP " %1, %1, %9\n\t" OP " %2, %2, %10\n\t" OP " %3, %3, %11\n\t"                      \
+            OP " %4, %4, %12\n\t" OP " %5, %5, %13\n\t" OP " %6, %6, %14\n\t" OP " %7, %7, %15\n\ts_branch 2f\n1:\n\t" \
+            OP " %0, %0, %16\n\t" OP " %1, %1, %17\n\t" OP " %2, %2, %18\n\t" OP " %3, %3, %19\n\t"                    \
+            OP " %4, %4, %20\n\t" OP " %5, %5, %21\n\t" OP " %6, %6, %22\n\t" OP " %7, %7, %23\n2:"                     \
+            : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3])           \
+            : "v"(H(0, QBASE)), "v"(H(1, QBASE)), "v"(H(2, QBASE)), "v"(H(3, QBASE)),                                  \
+              "v"(S(0, QBASE)), "v"(S(1, QBASE)), "v"(S(2, QBASE)), "v"(S(3, QBASE)),                                  \
+              "v"(H(0, QBASE + 1)), "v"(H(1, QBASE + 1)), "v"(H(2, QBASE + 1)), "v"(H(3, QBASE + 1)),                  \
+              "v"(S(0, QBASE + 1)), "v"(S(1, QBASE + 1)), "v"(S(2, QBASE + 1)), "v"(S(3, QBASE + 1)), "s"(q), "n"(QBASE) : "scc")
+        if constexpr (K & 1) BHW_UNI2W("v_sub_u32"); else BHW_UNI2W("v_add_u32");
+#undef BHW_UNI2W
+    } else {
+        tile_accumulate_uniform<K, OFF, QBASE, QBITS>(q, svh, h);
+        tile_accumulate_uniform<K, OFF, QBASE, QBITS>(q, sv, l);
+    }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { acc[i].hi = h[i]; acc[i].lo = l[i]; }
+    for (int i = 0; i < 4; ++i) { acc[i].hi = h[i]; acc[i].sum = l[i]; }
 }
 
 // image j of a lane sits K*j quadrants after image 0; OFF = extra quadrants of this half-period image (even K: K/2)
@@ -591,8 +621,8 @@ __device__ __forceinline__ void tile_accumulate(const int32_t (&sv)[4], Sum32 (&
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int32_t b = sv[(j * K + OFF) & 3];
-        if (K & 1) { acc[j].hi -= b >> 2; acc[j].lo -= b & 3; }
-        else       { acc[j].hi += b >> 2; acc[j].lo += b & 3; }
+        if (K & 1) { acc[j].hi -= b >> 2; acc[j].sum -= b; }
+        else       { acc[j].hi += b >> 2; acc[j].sum += b; }
     }
 }
 // Remaining rotations of one chain, k0 <= k < n_iter, as a rolled loop on a scalar counter: k0 and n_iter are wave-uniform, the

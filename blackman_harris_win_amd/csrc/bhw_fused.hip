@@ -137,7 +137,7 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win, BhwFo
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if constexpr (MODE == 2) acc[h][j] = Sum32{win.aa[0] >> 2, win.aa[0] & 3};
+            if constexpr (MODE == 2) acc[h][j] = sum32_first(win.aa[0]);
             else acc[h][j] = win.aa[0];
         }
     // slot -> (K, half-period image) as compile-time functions of the slot
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void k_fold_split(BhwWinCfg win, BhwFoldPlan p
         acc_t acc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if constexpr (MODE == 2) acc[j] = Sum32{win.aa[0] >> 2, win.aa[0] & 3};
+            if constexpr (MODE == 2) acc[j] = sum32_first(win.aa[0]);
             else acc[j] = win.aa[0];
         }
 #define BHW_FS_HARMONIC(K)                                                                                            \

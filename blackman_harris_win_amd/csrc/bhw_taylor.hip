@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void k_taylor_window_fold(BhwTaylorCfg t, B
     auto first = [&]() -> val_t {                                 // a_0
         if constexpr (ARITH == 2) {
             if constexpr (COMBINE == BHW_COMBINE_HLS) return Sum32{win.aa[0], 0};
-            else return Sum32{win.aa[0] >> 2, win.aa[0] & 3};
+            else return sum32_first(win.aa[0]);
         } else return (val_t)win.aa[0];
     };
     // generators by valuation v = 0, 1, 2 of the harmonic number (k = 1,3,5 | 2,6 | 4)

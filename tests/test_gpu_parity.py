@@ -319,6 +319,19 @@ def test_weights_at_the_edge_of_the_one_instruction_products(torch, w):
             assert np.array_equal(gpu_generate(pv, 0, n, B.ALGO_TABLE), O.generate_mt(O.from_bhw(pv), 0, n)), (aa, model)
 
 
+@pytest.mark.gpu
+def test_vhdl_rule_one_word_sums_at_the_bound(torch):
+    """VHDL cosine-sum in the tile kernel: with one-instruction products the W+2-bit sum is kept in ONE 32-bit word when the sum
+    of the (|a_k| + 1) stays below 2^31, in two words otherwise -- weights on either side of that bound, both signs of a_0."""
+    h = 1 << 28
+    n = 1 << 22
+    for a0 in ((1 << 29) - 8, (1 << 29) - 7, -((1 << 29) - 8), -((1 << 29) - 7)):
+        for harm in ([h, -h, h, -h, h, -h], [-h, -h, -h, -h, -h, -h], [h, h, h, h, h, h]):
+            for model in (B.MODEL_HLS, B.MODEL_CPP):
+                pv = B.make_params(7, 22, 32, aa=[a0] + harm, combine=B.COMBINE_VHDL, model=model)
+                assert np.array_equal(gpu_generate(pv, 0, n, B.ALGO_TABLE), O.generate_mt(O.from_bhw(pv), 0, n)), (a0, harm, model)
+
+
 def test_strategies_agree_on_random_whole_windows(torch):
     """Size-independent property: DIRECT (one CORDIC chain per harmonic per coefficient) and TABLE (shared table,
     folds, gather tiles) are different computations of the same integers -- whole windows must be identical."""
