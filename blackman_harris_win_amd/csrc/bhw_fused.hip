@@ -31,7 +31,10 @@ struct BhwFoldPlan {
     int64_t  x0;
     uint32_t n_iter, z_shr, z_shl, out_shr;
     uint32_t n_runs, phi_width, dat_width, ones_neg;
-    uint32_t fast_mul, pad0;                 // 1: every harmonic weight below 2^(W-3): one-instruction products (tile_harmonic FAST)
+    uint32_t fast_mul, k24;                  // 1: every harmonic weight below 2^(W-3): one-instruction products (tile_harmonic FAST);
+                                             // k24: first rotation the sign-product form of the narrow kernel is valid at (rot_mad24)
+    uint32_t run0_r0, run0_end;              // = r0[0], r_end[0], next to the other scalars: a one-run launch reads one block of arguments
+    uint32_t block, pad1;                    // threads per workgroup of this launch (k_fold_direct: 64 or 256)
     uint32_t r0[kFoldRunsMax];               // first ring index of each run
     uint32_t r_end[kFoldRunsMax];            // one past its last
     uint32_t wg_first[kFoldRunsMax + 1];     // first workgroup of each run; [n_runs] = grid size
@@ -67,9 +70,100 @@ __device__ __forceinline__ void chain_from(int64_t &x, int64_t &y, int32_t &z, i
 // start level.
 constexpr int kFoldLevels = (kPrefixMax < 32 ? kPrefixMax : 32) + 1;
 
-template <int NTERMS, int MODE, bool LOCKSTEP>
+//   FORM 2 (narrow): lockstep on 32-bit state, for configurations whose x, y, z fit 32-bit signed words (dat_width + out_shr <= 30).
+//          Every wave runs the shared prefixes of its own chains in its first NCH lanes -- all of them up to the first rotation at
+//          which ANY of them splits, so the hand-over is one wave-uniform level -- and broadcasts them with v_readlane: no LDS, no
+//          barrier, no wave waiting for another one's serial phase.  The per-leaf rotations take the EXEC-masked form of the table
+//          build (rot_narrow32 below: 9 plain VOP2 instructions and two scalar ones instead of v_mad_i64_i32 / v_alignbit_b32).
+// One rotation of a 32-bit signed state; k and lutk are scalars.  Every lane of the wave is active on entry and on exit (phase 2
+// runs whole waves: lanes beyond r_end compute and do not store).
+__device__ __forceinline__ void rot_narrow32(int32_t &x, int32_t &y, int32_t &z, int k, uint32_t lutk)
+{
+    int32_t a, b;
+    asm volatile("v_ashrrev_i32 %[a], %[k], %[y]\n\t"
+                 "v_ashrrev_i32 %[b], %[k], %[x]\n\t"
+                 "v_cmpx_gt_i32 vcc, 0, %[z]\n\t"
+                 "v_add_u32 %[x], %[x], %[a]\n\t"
+                 "v_sub_u32 %[y], %[y], %[b]\n\t"
+                 "v_add_u32 %[z], %[l], %[z]\n\t"
+                 "s_not_b64 exec, exec\n\t"
+                 "v_sub_u32 %[x], %[x], %[a]\n\t"
+                 "v_add_u32 %[y], %[y], %[b]\n\t"
+                 "v_subrev_u32 %[z], %[l], %[z]\n\t"
+                 "s_mov_b64 exec, -1"
+                 : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [a] "=&v"(a), [b] "=&v"(b)
+                 : [l] "s"(lutk), [k] "s"(k)
+                 : "vcc", "scc");
+}
+
+// The same rotation as sign products: x -= sg * (y >> k), y += sg * (x >> k), z -= sg * lut[k] with sg = +1 / -1 in three
+// v_mad_i32_i24 (24-bit factors, 32-bit addend): 8 vector instructions and no EXEC traffic.  Valid from rotation plan.k24 on, where
+// the shifted coordinates and the ROM word fit 24 bits (the launcher derives it from the widths; 2 for a 2^20-point 24-bit window).
+__device__ __forceinline__ void rot_mad24(int32_t &x, int32_t &y, int32_t &z, int k, uint32_t lutk)
+{
+    int32_t a, b, sg, ng;
+    asm volatile("v_ashrrev_i32 %[ng], 31, %[z]\n\t"
+                 "v_ashrrev_i32 %[a], %[k], %[y]\n\t"
+                 "v_ashrrev_i32 %[b], %[k], %[x]\n\t"
+                 "v_or_b32 %[sg], 1, %[ng]\n\t"
+                 "v_sub_u32 %[ng], 0, %[sg]\n\t"
+                 "v_mad_i32_i24 %[x], %[ng], %[a], %[x]\n\t"
+                 "v_mad_i32_i24 %[y], %[sg], %[b], %[y]\n\t"
+                 "v_mad_i32_i24 %[z], %[ng], %[l], %[z]"
+                 : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [a] "=&v"(a), [b] "=&v"(b), [sg] "=&v"(sg), [ng] "=&v"(ng)
+                 : [l] "s"(lutk), [k] "s"(k));
+}
+
+// Two / three chains in one statement, instruction by instruction side by side: a wave issues in order, and with one or two waves
+// per SIMD (a 2^20-point window is 2 048 waves on 1 024 SIMDs) the four dependent steps of a rotation (sign, +-1, negate, product)
+// stall it unless other chains' instructions sit in between.
+__device__ __forceinline__ void rot_mad24_x2(int32_t &x0, int32_t &y0, int32_t &z0, int32_t &x1, int32_t &y1, int32_t &z1, int k, uint32_t lutk)
+{
+    int32_t a0, b0, s0, n0, a1, b1, s1, n1;
+    asm volatile("v_ashrrev_i32 %[n0], 31, %[z0]\n\tv_ashrrev_i32 %[n1], 31, %[z1]\n\t"
+                 "v_ashrrev_i32 %[a0], %[k], %[y0]\n\tv_ashrrev_i32 %[a1], %[k], %[y1]\n\t"
+                 "v_or_b32 %[s0], 1, %[n0]\n\tv_or_b32 %[s1], 1, %[n1]\n\t"
+                 "v_ashrrev_i32 %[b0], %[k], %[x0]\n\tv_ashrrev_i32 %[b1], %[k], %[x1]\n\t"
+                 "v_sub_u32 %[n0], 0, %[s0]\n\tv_sub_u32 %[n1], 0, %[s1]\n\t"
+                 "v_mad_i32_i24 %[y0], %[s0], %[b0], %[y0]\n\tv_mad_i32_i24 %[y1], %[s1], %[b1], %[y1]\n\t"
+                 "v_mad_i32_i24 %[x0], %[n0], %[a0], %[x0]\n\tv_mad_i32_i24 %[x1], %[n1], %[a1], %[x1]\n\t"
+                 "v_mad_i32_i24 %[z0], %[n0], %[l], %[z0]\n\tv_mad_i32_i24 %[z1], %[n1], %[l], %[z1]"
+                 : [x0] "+v"(x0), [y0] "+v"(y0), [z0] "+v"(z0), [x1] "+v"(x1), [y1] "+v"(y1), [z1] "+v"(z1),
+                   [a0] "=&v"(a0), [b0] "=&v"(b0), [s0] "=&v"(s0), [n0] "=&v"(n0), [a1] "=&v"(a1), [b1] "=&v"(b1), [s1] "=&v"(s1), [n1] "=&v"(n1)
+                 : [l] "s"(lutk), [k] "s"(k));
+}
+__device__ __forceinline__ void rot_mad24_x3(int32_t &x0, int32_t &y0, int32_t &z0, int32_t &x1, int32_t &y1, int32_t &z1,
+                                             int32_t &x2, int32_t &y2, int32_t &z2, int k, uint32_t lutk)
+{
+    int32_t a0, b0, s0, n0, a1, b1, s1, n1, a2, b2, s2, n2;
+    asm volatile("v_ashrrev_i32 %[n0], 31, %[z0]\n\tv_ashrrev_i32 %[n1], 31, %[z1]\n\tv_ashrrev_i32 %[n2], 31, %[z2]\n\t"
+                 "v_ashrrev_i32 %[a0], %[k], %[y0]\n\tv_ashrrev_i32 %[a1], %[k], %[y1]\n\tv_ashrrev_i32 %[a2], %[k], %[y2]\n\t"
+                 "v_or_b32 %[s0], 1, %[n0]\n\tv_or_b32 %[s1], 1, %[n1]\n\tv_or_b32 %[s2], 1, %[n2]\n\t"
+                 "v_ashrrev_i32 %[b0], %[k], %[x0]\n\tv_ashrrev_i32 %[b1], %[k], %[x1]\n\tv_ashrrev_i32 %[b2], %[k], %[x2]\n\t"
+                 "v_sub_u32 %[n0], 0, %[s0]\n\tv_sub_u32 %[n1], 0, %[s1]\n\tv_sub_u32 %[n2], 0, %[s2]\n\t"
+                 "v_mad_i32_i24 %[y0], %[s0], %[b0], %[y0]\n\tv_mad_i32_i24 %[y1], %[s1], %[b1], %[y1]\n\tv_mad_i32_i24 %[y2], %[s2], %[b2], %[y2]\n\t"
+                 "v_mad_i32_i24 %[x0], %[n0], %[a0], %[x0]\n\tv_mad_i32_i24 %[x1], %[n1], %[a1], %[x1]\n\tv_mad_i32_i24 %[x2], %[n2], %[a2], %[x2]\n\t"
+                 "v_mad_i32_i24 %[z0], %[n0], %[l], %[z0]\n\tv_mad_i32_i24 %[z1], %[n1], %[l], %[z1]\n\tv_mad_i32_i24 %[z2], %[n2], %[l], %[z2]"
+                 : [x0] "+v"(x0), [y0] "+v"(y0), [z0] "+v"(z0), [x1] "+v"(x1), [y1] "+v"(y1), [z1] "+v"(z1), [x2] "+v"(x2), [y2] "+v"(y2), [z2] "+v"(z2),
+                   [a0] "=&v"(a0), [b0] "=&v"(b0), [s0] "=&v"(s0), [n0] "=&v"(n0), [a1] "=&v"(a1), [b1] "=&v"(b1), [s1] "=&v"(s1), [n1] "=&v"(n1),
+                   [a2] "=&v"(a2), [b2] "=&v"(b2), [s2] "=&v"(s2), [n2] "=&v"(n2)
+                 : [l] "s"(lutk), [k] "s"(k));
+}
+// one rotation of all NCH chains of a lane (NCH = 2, 3, 5, 6, 9): groups of three, then what is left
+template <int NCH>
+__device__ __forceinline__ void rot_mad24_all(int32_t (&x)[NCH], int32_t (&y)[NCH], int32_t (&z)[NCH], int k, uint32_t lutk)
+{
+    constexpr int N3 = NCH / 3 * 3;
+#pragma unroll
+    for (int c = 0; c < N3; c += 3) rot_mad24_x3(x[c], y[c], z[c], x[c + 1], y[c + 1], z[c + 1], x[c + 2], y[c + 2], z[c + 2], k, lutk);
+    if constexpr (NCH - N3 == 2) rot_mad24_x2(x[N3], y[N3], z[N3], x[N3 + 1], y[N3 + 1], z[N3 + 1], k, lutk);
+    if constexpr (NCH - N3 == 1) rot_mad24(x[N3], y[N3], z[N3], k, lutk);
+}
+
+template <int NTERMS, int MODE, int FORM>
 __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win, BhwFoldPlan plan, int32_t *__restrict__ out)
 {
+    constexpr bool LOCKSTEP = FORM == 1;
     using acc_t = typename std::conditional<MODE == 2, Sum32, int32_t>::type;
     constexpr int NCH = fold_chains(NTERMS);
     constexpr int kTasks = (kFoldBlock / 64) * NCH;
@@ -83,15 +177,41 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win, BhwFo
     const uint32_t E = 1u << lq, emask = E - 1u, H = E >> 1;
     const uint32_t W = plan.dat_width;
     const int n_iter = (int)plan.n_iter;
-    uint32_t run = 0;                                                     // scalar search: at most kFoldRunsMax runs
-    while (run + 1u < plan.n_runs && blockIdx.x >= plan.wg_first[run + 1u]) ++run;
-    const uint32_t wg_r0 = plan.r0[run] + (blockIdx.x - plan.wg_first[run]) * blockDim.x;
-    const uint32_t r_end = plan.r_end[run];
-    const uint32_t n_waves = blockDim.x >> 6;
+    // the run of this workgroup.  One run (a whole window) reads its bounds at fixed kernel-argument offsets, in the same batch of
+    // scalar loads as everything else; the search (at most kFoldRunsMax runs) costs two more dependent round trips of ~0.2 us each
+    uint32_t run_r0 = plan.run0_r0, r_end = plan.run0_end, run_wg = 0u;
+    uint32_t lutv_early = 0u;
+    if constexpr (FORM == 2) {
+        // lane k holds lut[k]: requested from the argument segment (plan follows win, 8-byte aligned) by hand, next to the scalar
+        // loads, and waited for where the prefix first needs it -- the compiler would issue it after the scalar batch has returned
+        constexpr uint32_t kPlanOffset = (uint32_t)((sizeof(BhwWinCfg) + 7u) & ~7u);
+        const char *args = (const char *)__builtin_amdgcn_kernarg_segment_ptr() + kPlanOffset;   // (constant address space: C-style cast)
+        const uint32_t off = (threadIdx.x & 31u) << 2;
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(lutv_early) : "v"(off), "s"(args));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (FORM == 2) {
+        // short launches: every kernel argument the common path reads, requested before the first wait (left alone the compiler
+        // fetches them in two or three dependent batches, a scalar-cache miss each)
+        asm volatile("" :: "s"(plan.n_runs), "s"(run_r0), "s"(r_end), "s"(plan.x0), "s"(plan.n_iter), "s"(plan.z_shr), "s"(plan.z_shl),
+                     "s"(plan.out_shr), "s"(plan.phi_width), "s"(plan.dat_width), "s"(plan.ones_neg), "s"(plan.fast_mul), "s"(plan.k24), "s"(plan.block),
+                     "s"(win.aa[0]), "s"(win.aa[1]), "s"(win.aa[NTERMS > 2 ? 2 : 0]), "s"(win.aa[NTERMS > 3 ? 3 : 0]),
+                     "s"(win.aa[NTERMS > 4 ? 4 : 0]), "s"(win.aa[NTERMS > 5 ? 5 : 0]), "s"(win.aa[NTERMS > 6 ? 6 : 0]), "s"(out));
+    }
+    if (plan.n_runs > 1u) {
+        uint32_t run = 0;
+        while (run + 1u < plan.n_runs && blockIdx.x >= plan.wg_first[run + 1u]) ++run;
+        run_r0 = plan.r0[run];
+        r_end = plan.r_end[run];
+        run_wg = plan.wg_first[run];
+    }
+    const uint32_t wg_r0 = run_r0 + (blockIdx.x - run_wg) * plan.block;
+    const uint32_t n_waves = plan.block >> 6;
     const uint32_t z_shr = plan.z_shr, z_shl = plan.z_shl, out_shr = plan.out_shr;
 
     // ---- phase 1: shared rotation prefix of every (wave, chain) ----
     // chain slot c -> harmonic K and half-period image: (1,0) (1,1) (2) (3,0) (3,1) (4) (5,0) (5,1) (6)
+    if constexpr (FORM != 2) {
     if (threadIdx.x < n_waves * NCH) {
         const uint32_t wv = threadIdx.x / NCH, c = threadIdx.x % NCH;
         const uint32_t K = 2u * (c / 3u) + 1u + (c % 3u == 2u ? 1u : 0u);
@@ -126,11 +246,16 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win, BhwFo
         gk[threadIdx.x] = k;
     }
     __syncthreads();
+    }
 
     // ---- phase 2: one lane per r ----
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t r = wg_r0 + threadIdx.x;
-    const uint32_t lutv = plan.lut[threadIdx.x & 31u];                    // lane k (and k + 32) holds lut[k]
+    uint32_t lutv;                                                        // lane k (and k + 32) holds lut[k]
+    if constexpr (FORM == 2) {
+        lutv = lutv_early;
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(lutv));
+    } else lutv = plan.lut[threadIdx.x & 31u];
     const bool fast = MODE != 2 && plan.fast_mul != 0u;
     acc_t acc[2][4];
 #pragma unroll
@@ -177,8 +302,88 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win, BhwFo
 #pragma unroll
         for (int c = 0; c < NCH; ++c) cs[c] = make_int2((int32_t)(x[c] >> out_shr), (int32_t)(y[c] >> out_shr));
     }
+    if constexpr (FORM == 2) {
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t rf = wg_r0 + (wave << 6);                          // first ring lane of this wave
+        // prefixes: lane c < NCH follows the group of chain c; the loop ends for all of them at the first split
+        const uint32_t pc = lane < (uint32_t)NCH ? lane : 0u;
+        const uint32_t pK = 2u * (pc / 3u) + 1u + (pc % 3u == 2u ? 1u : 0u), ph = (pc % 3u == 1u) ? 1u : 0u;
+        const uint32_t t0 = (pK * rf + ph * H) & emask;
+        const uint32_t tl = t0 + 63u * pK;
+        const uint32_t z0f = (t0 >> z_shr) << z_shl;
+        const bool whole = tl <= emask;                                   // wrapped groups are not contiguous in angle: no sharing
+        const uint32_t span = (whole && lane < (uint32_t)NCH) ? ((tl >> z_shr) << z_shl) - z0f : 0u;   // idle lanes never split
+        int32_t px = (int32_t)plan.x0, py = (int32_t)plan.x0;            // after rotation 0 (z0 >= 0 always adds)
+        int32_t pz = (int32_t)(z0f - (uint32_t)__builtin_amdgcn_readlane((int)lutv, 0));
+        int kc = 1;
+        const int k_stop = __builtin_amdgcn_ballot_w64(!whole && lane < (uint32_t)NCH) != 0ull ? 1 : n_iter;   // a wrapped group: no prefix
+        // Rotations 1 .. kc - 1 on the group states, until some group splits (sign of z differs at its two end leaves): one statement,
+        // so that the serial depth of a level is what the arithmetic needs -- both outcomes of z side by side and one select, the
+        // split test of the next level on the selected z, the branch on a compare issued four instructions earlier -- instead of the
+        // compare / mask / branch ladder the compiler builds around a wave vote (190 -> ~90 cycles per level; every wave of a short
+        // launch starts with ~10 of these).  Two instructions sit between a lane read or compare that writes scalar registers and
+        // the vector instruction that reads them (gfx940+ hazard; nothing inserts no-ops inside a statement).
+        {
+            int32_t t, a, b, za, zb, xa, xb, ya, yb;
+            uint32_t sl;
+            uint64_t ng;
+            asm volatile("s_cmp_ge_i32 %[kc], %[ks]\n\t"
+                         "s_cbranch_scc1 1f\n"
+                         "0:\n\t"
+                         "v_add_u32 %[t], %[pz], %[sp]\n\t"
+                         "v_readlane_b32 %[sl], %[lv], %[kc]\n\t"
+                         "v_xor_b32 %[t], %[t], %[pz]\n\t"
+                         "v_cmp_gt_i32_e64 %[ng], 0, %[pz]\n\t"
+                         "v_cmp_gt_i32 vcc, 0, %[t]\n\t"
+                         "v_ashrrev_i32 %[a], %[kc], %[py]\n\t"
+                         "v_ashrrev_i32 %[b], %[kc], %[px]\n\t"
+                         "v_add_u32 %[za], %[sl], %[pz]\n\t"
+                         "v_subrev_u32 %[zb], %[sl], %[pz]\n\t"
+                         "s_cbranch_vccnz 1f\n\t"
+                         "v_cndmask_b32_e64 %[pz], %[zb], %[za], %[ng]\n\t"
+                         "v_add_u32 %[xa], %[px], %[a]\n\t"
+                         "v_sub_u32 %[xb], %[px], %[a]\n\t"
+                         "v_sub_u32 %[ya], %[py], %[b]\n\t"
+                         "v_add_u32 %[yb], %[py], %[b]\n\t"
+                         "s_add_u32 %[kc], %[kc], 1\n\t"
+                         "v_cndmask_b32_e64 %[px], %[xb], %[xa], %[ng]\n\t"
+                         "v_cndmask_b32_e64 %[py], %[yb], %[ya], %[ng]\n\t"
+                         "s_cmp_lt_i32 %[kc], %[ks]\n\t"
+                         "s_cbranch_scc1 0b\n"
+                         "1:"
+                         : [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [kc] "+s"(kc), [t] "=&v"(t), [a] "=&v"(a), [b] "=&v"(b),
+                           [za] "=&v"(za), [zb] "=&v"(zb), [xa] "=&v"(xa), [xb] "=&v"(xb), [ya] "=&v"(ya), [yb] "=&v"(yb),
+                           [sl] "=&s"(sl), [ng] "=&s"(ng)
+                         : [sp] "v"(span), [lv] "v"(lutv), [ks] "s"(k_stop)
+                         : "vcc", "scc");
+        }
+        const uint32_t pdz = (uint32_t)pz - z0f;
+        int32_t x[NCH], y[NCH], z[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            x[c] = __builtin_amdgcn_readlane(px, c);
+            y[c] = __builtin_amdgcn_readlane(py, c);
+            const uint32_t t = ((uint32_t)slot_K(c) * r + slot_h(c) * H) & emask;
+            z[c] = (int32_t)(((t >> z_shr) << z_shl) + (uint32_t)__builtin_amdgcn_readlane((int)pdz, c));
+        }
+        int k = kc;
+        const int k24 = (int)plan.k24 < n_iter ? (int)plan.k24 : n_iter;
+#pragma unroll 1
+        for (; k < k24; ++k) {                                            // (only waves whose prefix ended before rotation k24)
+            const uint32_t lutk = (uint32_t)__builtin_amdgcn_readlane((int)lutv, k);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) rot_narrow32(x[c], y[c], z[c], k, lutk);
+        }
+#pragma unroll 1
+        for (; k < n_iter; ++k) {
+            const uint32_t lutk = (uint32_t)__builtin_amdgcn_readlane((int)lutv, k);
+            rot_mad24_all<NCH>(x, y, z, k, lutk);
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) cs[c] = make_int2(x[c] >> out_shr, y[c] >> out_shr);
+    }
     auto chain = [&](const uint32_t slot, const uint32_t K, const uint32_t hodd) -> int2 {
-        if constexpr (LOCKSTEP) return cs[slot];
+        if constexpr (FORM != 0) return cs[slot];
         const uint32_t i = wave * NCH + slot;                             // scalar: the parked state is read as a broadcast
         const int k0 = __builtin_amdgcn_readfirstlane(gk[i]);
         int64_t x = gx[k0][i], y = gy[k0][i];
@@ -264,10 +469,15 @@ __global__ __launch_bounds__(256) void k_fold_split(BhwWinCfg win, BhwFoldPlan p
     const uint32_t E = 1u << lq, emask = E - 1u, H = E >> 1;
     const uint32_t W = plan.dat_width;
     const int n_iter = (int)plan.n_iter;
-    uint32_t run = 0;
-    while (run + 1u < plan.n_runs && blockIdx.x >= plan.wg_first[run + 1u]) ++run;
-    const uint32_t wg_r0 = plan.r0[run] + (blockIdx.x - plan.wg_first[run]) * 64u;      // 64 ring lanes per workgroup
-    const uint32_t r_end = plan.r_end[run];
+    uint32_t run_r0 = plan.run0_r0, r_end = plan.run0_end, run_wg = 0u;     // (see k_fold_direct)
+    if (plan.n_runs > 1u) {
+        uint32_t run = 0;
+        while (run + 1u < plan.n_runs && blockIdx.x >= plan.wg_first[run + 1u]) ++run;
+        run_r0 = plan.r0[run];
+        r_end = plan.r_end[run];
+        run_wg = plan.wg_first[run];
+    }
+    const uint32_t wg_r0 = run_r0 + (blockIdx.x - run_wg) * 64u;          // 64 ring lanes per workgroup
     const uint32_t z_shr = plan.z_shr, z_shl = plan.z_shl, out_shr = plan.out_shr;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     const uint32_t r = wg_r0 + lane;
@@ -427,15 +637,30 @@ int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg 
         wg += (runs[i].r_end - runs[i].r0 + block - 1u) / block;
     }
     plan.wg_first[n_runs] = wg;
+    plan.block = block;
+    plan.run0_r0 = plan.r0[0];
+    plan.run0_end = plan.r_end[0];
     if (!wg) return 0;
     const int mode = (w.combine != BHW_COMBINE_HLS) ? 2 : (c.ones_neg ? 1 : 0);
     const dim3 grid(wg), blk(block);
     // fewer than ~4 waves per SIMD in the whole launch: latency-bound, walk the chains in lockstep
     const bool lockstep = total <= (1u << 18);
+    // ... on 32-bit state with in-wave prefixes when x, y (|.| < 2^(W + out_shr - 1)) and z (the quarter circle) fit signed words
+    const bool narrow = lockstep && c.dat_width + c.out_shr <= 30u && c.phi_width - 2u - c.z_shr + c.z_shl <= 30u;
+    {
+        // |x|, |y| < 2^B, B = W + out_shr - 1: (x >> k) fits 24 signed bits from k = B - 23 on; the ROM word from the first lut[k] < 2^23 on
+        const int B = (int)(c.dat_width + c.out_shr) - 1;
+        uint32_t k24 = B > 23 ? (uint32_t)(B - 23) : 1u;
+        while (k24 < c.n_iter && (uint32_t)c.lut[k24] >= (1u << 23)) ++k24;
+        plan.k24 = k24;
+    }
     // short launches, form of the kernel: 2 = chains split over four waves per 64 lanes (k_fold_split), 1 = lockstep, 0 = sequential
     // measured per call (profiles/r02_ab_fused_lockstep.txt): split 7.8 / lockstep 9.0 us at 2^13 lanes (BH-7 2^16), 6.9 / 7.7 at
     // 2^15 (BH-5 2^18), 9.7 / 9.7 at 2^16, 9.0 / 8.2 at 2^17 (BH-4 2^20): split up to 2^15 lanes, lockstep up to 2^18
-    const bool split = total <= (1u << 15);
+    // (round 3, tools/bench_short_graph.py: where the narrow form applies it beats the split one at every size for windows of up to
+    // five terms -- 4.4 / 4.5 / 4.8 against 5.1 / 5.2 / 5.5 us at 2^14 / 2^16 / 2^18 points of BH-4 -- and loses to it with the nine
+    // chains of a 7-term window, 6.8 against 6.6 us at 2^16)
+    const bool split = total <= (1u << 15) && !(narrow && w.n_terms <= 5);
     dim3 grid_s(0), blk_s(256);
     if (split) {
         uint32_t wgs = 0;
@@ -449,8 +674,9 @@ int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg 
 #define BHW_FD_NT_M(NT, M)                                                                                  \
     do {                                                                                                    \
         if (split) BHW_LAUNCH((k_fold_split<NT, M>), grid_s, blk_s, 0, st, w, plan, d_out);               \
-        else if (lockstep) BHW_LAUNCH((k_fold_direct<NT, M, true>), grid, blk, 0, st, w, plan, d_out); \
-        else          BHW_LAUNCH((k_fold_direct<NT, M, false>), grid, blk, 0, st, w, plan, d_out);          \
+        else if (narrow)   BHW_LAUNCH((k_fold_direct<NT, M, 2>), grid, blk, 0, st, w, plan, d_out);      \
+        else if (lockstep) BHW_LAUNCH((k_fold_direct<NT, M, 1>), grid, blk, 0, st, w, plan, d_out);      \
+        else               BHW_LAUNCH((k_fold_direct<NT, M, 0>), grid, blk, 0, st, w, plan, d_out);      \
     } while (0)
 #define BHW_FD_NT(NT)                                                                                       \
     do {                                                                                                    \

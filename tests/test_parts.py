@@ -155,7 +155,11 @@ FUSED_CASES = []
 for _model in (B.MODEL_HLS, B.MODEL_CPP, B.MODEL_VHDL):
     for _combine in (B.COMBINE_HLS, B.COMBINE_VHDL):
         for _win, _pw, _w in [(1, 9, 16), (2, 12, 24), (3, 13, 12), (4, 16, 24), (5, 14, 30), (7, 15, 32), (7, 12, 31), (4, 10, 8),
-                              (7, 18, 18), (5, 17, 13), (7, 20, 16), (4, 20, 24)]:
+                              (7, 18, 18), (5, 17, 13), (7, 20, 16), (4, 20, 24),
+                              # either side of the 32-bit-state form of the fused kernel (dat_width + out_shr <= 30): its in-wave
+                              # prefixes, the sign-product rotation from rotation k24 on and the EXEC-masked one before it (waves
+                              # whose groups wrap start at rotation 1)
+                              (7, 16, 28), (5, 19, 28), (4, 18, 27), (3, 16, 29), (2, 14, 26), (5, 12, 10)]:
             if _model == B.MODEL_HLS and _pw > _w + 2:
                 continue
             FUSED_CASES.append((_model, _combine, _win, _pw, _w))
