@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win, BhwFo
         lutv = lutv_early;
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(lutv));
     } else lutv = plan.lut[threadIdx.x & 31u];
-    const bool fast = MODE != 2 && plan.fast_mul != 0u;
+    const bool fast = plan.fast_mul != 0u;                                // (VHDL rule too: (q + 1) >> 1 on q = mul_hi, two-word sums)
     acc_t acc[2][4];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -394,9 +394,9 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win, BhwFo
     };
 #define BHW_FD_TERM(K, HH, CS, ACC, OFF)                                                                 \
     if (fast) {                                                           /* scalar branch */        \
-        tile_harmonic<K, MODE, ring_qbase(K, HH), ring_qbits(K, HH), MODE != 2>(cfg, (int32_t)((uint32_t)win.aa[K] << (34u - W)), W, CS, \
+        tile_harmonic<K, MODE, ring_qbase(K, HH), ring_qbits(K, HH), true>(cfg, (int32_t)((uint32_t)win.aa[K] << (34u - W)), W, CS, \
                                                                                 ((uint32_t)K * (r + (uint32_t)HH * H)) >> lq, sv); \
-        tile_accumulate<K, OFF, MODE != 2>(sv, ACC);                                                 \
+        tile_accumulate<K, OFF, true>(sv, ACC);                                                 \
     } else {                                                                                         \
         tile_harmonic<K, MODE, ring_qbase(K, HH), ring_qbits(K, HH)>(cfg, win.aa[K], W, CS, ((uint32_t)K * (r + (uint32_t)HH * H)) >> lq, sv); \
         tile_accumulate<K, OFF>(sv, ACC);                                                            \
@@ -412,9 +412,9 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win, BhwFo
             BHW_FD_TERM(K, 1, cs1, acc[1], 0)                                                        \
         } else {                                                                                     \
             if (fast) {                                                                              \
-                tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0), MODE != 2>(cfg, (int32_t)((uint32_t)win.aa[K] << (34u - W)), W, cs0, ((uint32_t)K * r) >> lq, sv); \
-                tile_accumulate<K, 0, MODE != 2>(sv, acc[0]);                                        \
-                tile_accumulate<K, K / 2, MODE != 2>(sv, acc[1]);                                    \
+                tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0), true>(cfg, (int32_t)((uint32_t)win.aa[K] << (34u - W)), W, cs0, ((uint32_t)K * r) >> lq, sv); \
+                tile_accumulate<K, 0, true>(sv, acc[0]);                                        \
+                tile_accumulate<K, K / 2, true>(sv, acc[1]);                                    \
             } else {                                                                                 \
                 tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0)>(cfg, win.aa[K], W, cs0, ((uint32_t)K * r) >> lq, sv); \
                 tile_accumulate<K, 0>(sv, acc[0]);                                                   \
@@ -620,7 +620,7 @@ int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg 
     plan.phi_width = c.phi_width;
     plan.dat_width = c.dat_width;
     plan.ones_neg = c.ones_neg;
-    plan.fast_mul = (w.combine == BHW_COMBINE_HLS && c.dat_width >= 3) ? 1u : 0u;
+    plan.fast_mul = c.dat_width >= 3 ? 1u : 0u;                          // either cosine-sum rule (the VHDL one keeps its two-word sums)
     for (uint32_t k = 1; k < w.n_terms && plan.fast_mul; ++k) {
         const int64_t lim = (int64_t)1 << (c.dat_width - 3);
         if ((int64_t)w.aa[k] >= lim || (int64_t)w.aa[k] <= -lim) plan.fast_mul = 0u;

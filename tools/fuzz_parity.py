@@ -89,7 +89,7 @@ def fuzz(budget=60.0, seed=1, max_cases=None, max_count=1 << 25, max_pw=25, verb
         else:             n0, count = int(rng.integers(0, 4 * n)), int(rng.integers(1, min(4 * n, 300000) + 1))
         count = min(count, (1 << 17) if taylor else max_count)              # the Taylor oracle evaluates its ROM in binary128 per sample
         if taylor and count < n <= (1 << 17) and mode < 0.5: n0, count = 0, n
-        algo = int(rng.choice([B.ALGO_AUTO, B.ALGO_DIRECT, B.ALGO_TABLE]))
+        algo = int(rng.choice([B.ALGO_AUTO, B.ALGO_DIRECT, B.ALGO_TABLE, B.ALGO_FUSED]))
         desc = dict(win=win, pw=pw, w=w, model=model, combine=combine, prec=prec, aa=aa, taylor=taylor, lut=lut, n0=n0, count=count, algo=algo)
         try:
             got = bhw.generate(p, n0, count, algo=algo).cpu().numpy()
