@@ -157,7 +157,7 @@ def test_headline_kernels_have_no_scratch():
         res = json.load(f)
     headline = ["k_table_build_mirror<32, 3>", "k_table_build_mirror<32, 2>", "k_table_build_mirror<31, 3>", "k_table_combine_tile<15, 2, 3, true, false>", "k_table_combine_tile<15, 0, 3, true, false>",
                 "k_table_combine_tile<15, 0, 2, true, false>", "k_table_combine_tile<15, 1, 2, true, false>", "k_table_combine_tile<15, 0, 2, false, false>",
-                "k_fold_direct<7, 0, false>", "k_fold_direct<4, 0, true>", "k_fold_split<4, 0>", "k_runlength_window<7, 1, true>"]
+                "k_fold_direct<7, 0, 0>", "k_fold_direct<4, 0, 2>", "k_fold_direct<4, 0, 1>", "k_fold_split<4, 0>", "k_runlength_window<7, 1, true>"]
     for name in headline:
         assert name in res, name
     for name, r in res.items():                                      # no kernel of the library uses scratch
