@@ -610,8 +610,10 @@ __global__ __launch_bounds__(kRlBlock) void k_runlength_window(BhwCordicCfg cfg,
                 if (i) {
 #define BHW_RL_STEP(K)                                                                                                   \
                     if constexpr (NTERMS > K) {                                                                          \
-                        if (__builtin_amdgcn_ballot_w64(brk[K] == i)) {            /* wave-uniform: usually nobody */   \
-                            const bool mine = brk[K] == i;                                                              \
+                        uint32_t bk = brk[K];                                                                           \
+                        asm volatile("" : "+v"(bk));   /* the vote stays here: hoisted, the 6 x 15 masks of a sweep spill */ \
+                        if (__builtin_amdgcn_ballot_w64(bk == i)) {                /* wave-uniform: usually nobody */   \
+                            const bool mine = bk == i;                                                                  \
                             _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[j] += mine ? dlt[K][j] : 0;               \
                         }                                                                                               \
                     }
