@@ -379,6 +379,8 @@ def main():
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
+    ev0.record()                                   # torch creates the HIP event handle at the first record(): not inside the timed region
+    ev1.record()                                   # (two hipEventCreate calls cost ~25 us there -- 1 % of a 20-step run)
     elapsed = timed_steps(step_with_events, args.steps, 0, barrier, torch.cuda.synchronize, allreduce_max)
     dev_ms = ev0.elapsed_time(ev1) / args.steps
     dev_ms = allreduce_max(dev_ms)
