@@ -4,7 +4,7 @@ Every case draws a parameter set (all bit-models, both cosine-sum rules, CORDIC 
 extension, random integer weights, widths 8..32, lengths 2^4..2^24), a stream range and a strategy, generates it through
 the C ABI and compares bit-for-bit with the oracle (threaded via oracle/libcpubaseline.so).  One case in eight exercises
 the variant generators instead (cordic_dds48 / cordic_dds_scaled through bhw_sincos_device, cordic_atan2).
-usage: fuzz_parity.py <seconds> [seed]"""
+usage: fuzz_parity.py <seconds> [seed [max_pw]]"""
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -109,9 +109,10 @@ def fuzz(budget=60.0, seed=1, max_cases=None, max_count=1 << 25, max_pw=25, verb
 if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    max_pw = int(sys.argv[3]) if len(sys.argv) > 3 else 25          # e.g. 20: short windows only (the fused kernels' domain)
     t0 = time.time()
     try:
-        cases, samples, by = fuzz(budget, seed)
+        cases, samples, by = fuzz(budget, seed, max_pw=max_pw)
     except Mismatch as e:
         print("MISMATCH", e.args[0]); sys.exit(1)
     print("fuzz ok: %d cases, %d coefficients compared bit-for-bit in %.0f s (seed %d) on %s" % (cases, samples, time.time() - t0, seed, torch.cuda.get_device_name(0)))
