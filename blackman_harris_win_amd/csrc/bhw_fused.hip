@@ -645,8 +645,10 @@ int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg 
     const dim3 grid(wg), blk(block);
     // fewer than ~4 waves per SIMD in the whole launch: latency-bound, walk the chains in lockstep
     const bool lockstep = total <= (1u << 18);
-    // ... on 32-bit state with in-wave prefixes when x, y (|.| < 2^(W + out_shr - 1)) and z (the quarter circle) fit signed words
-    const bool narrow = lockstep && c.dat_width + c.out_shr <= 30u && c.phi_width - 2u - c.z_shr + c.z_shl <= 30u;
+    // on 32-bit state with in-wave prefixes when x, y (|.| < 2^(W + out_shr - 1)) and z (the quarter circle) fit signed words -- at
+    // every launch size: where the chip is full the form still wins a little over the 64-bit one with its own split level per chain
+    // (BH-4 2^22 / 24-bit 16.1 -> 15.2 us, BH-5 17.7 -> 17.4)
+    const bool narrow = c.dat_width + c.out_shr <= 30u && c.phi_width - 2u - c.z_shr + c.z_shl <= 30u;
     {
         // |x|, |y| < 2^B, B = W + out_shr - 1: (x >> k) fits 24 signed bits from k = B - 23 on; the ROM word from the first lut[k] < 2^23 on
         const int B = (int)(c.dat_width + c.out_shr) - 1;

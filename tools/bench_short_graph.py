@@ -12,7 +12,7 @@ import torch  # noqa: E402
 import blackman_harris_win_amd as bhw  # noqa: E402
 from blackman_harris_win_amd import binding as B  # noqa: E402
 
-CASES = [(4, 14, 24), (4, 16, 24), (4, 18, 24), (4, 20, 24), (5, 18, 24), (7, 16, 28), (7, 16, 32), (3, 18, 16), (7, 19, 24), (2, 16, 16)]
+CASES = [(4, 14, 24), (4, 16, 24), (4, 18, 24), (4, 20, 24), (5, 18, 24), (7, 16, 28), (7, 16, 32), (3, 18, 16), (7, 19, 24), (2, 16, 16), (4, 21, 24), (4, 22, 24), (5, 22, 24), (5, 21, 28), (3, 22, 20)]
 
 
 def replay_us(gen, p, n, out):
