@@ -157,13 +157,32 @@ def launch_check(args, rank, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    t_own = time.perf_counter()
     elapsed = timed_steps(lambda: time.sleep(0.002 * (rank + 1)), args.steps, args.warmup,
                           dist.barrier if world > 1 else (lambda: None), lambda: None, allreduce_max)
+    own_ms = 0.002 * (rank + 1) * 1e3                       # this rank's own step time (stands in for the device time per step)
+    del t_own
+    group = group_record(dist if world > 1 else None, torch, "cpu", world, "gloo", own_ms)
     if rank == 0:
-        print(json.dumps({"launch_check": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": args.scaling,
-                          "ms_per_step": elapsed / args.steps * 1e3, "shard_of_last_rank": list(shard_for(world - 1))}), flush=True)
+        print(json.dumps(dict({"launch_check": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": args.scaling,
+                               "ms_per_step": elapsed / args.steps * 1e3, "shard_of_last_rank": list(shard_for(world - 1))}, **group)), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def group_record(dist, torch, device, world, backend, own_device_ms):
+    """What the process group itself reports, so a scaling record can be checked against it: `ranks_seen` = all-reduce SUM of 1
+    over the group (must equal n_gpus), `device_ms_per_step_by_rank` = every rank's own device time per step (all-gather), and the
+    backend name.  Collectives on the timing path only -- the data path has none."""
+    if dist is None:
+        return {"ranks_seen": 1, "device_ms_per_step_by_rank": [own_device_ms], "backend": None}
+    one = torch.ones(1, dtype=torch.float64, device=device)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    mine = torch.tensor([own_device_ms], dtype=torch.float64, device=device)
+    every = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+    dist.all_gather(every, mine)
+    return {"ranks_seen": int(round(float(one.item()))), "device_ms_per_step_by_rank": [float(t.item()) for t in every],
+            "backend": backend + (" (RCCL)" if backend == "nccl" else "")}
 
 
 def device_times(step, steps, torch):
@@ -335,7 +354,13 @@ def main():
     else:
         n0, count = shard_for(rank)
         out = torch.empty(count, dtype=torch.int32, device=dev)
-        ws_bytes = B.lib().bhw_workspace_bytes(ctypes.byref(params), n0, count, algo)
+        # scratch: sized for the table format this configuration uses once bhw_prepare_device has settled it (16.5 MiB of nibble
+        # entries + records for the headline window; the format-independent bound bhw_workspace_bytes is 128 MiB)
+        bhw.prepare(params)
+        ex_q = B.BhwExec()
+        ex_q.struct_size = ctypes.sizeof(B.BhwExec)
+        ex_q.algo = algo
+        ws_bytes = B.lib().bhw_workspace_bytes_ex(ctypes.byref(params), n0, count, ctypes.byref(ex_q))
         workspace = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
         units_per_step = world * count
         my_units = count
@@ -370,6 +395,9 @@ def main():
     # steps after idle run up to ~10 % slower, and a cold box needs about a second of load before the rate is flat
     step()
     torch.cuda.synchronize()
+    # the same K steps straight after W warm-up steps, BEFORE the ramp: what a cold device gives (DVFS), printed beside the
+    # ramped figure so the effect of the ramp is in the record and not in prose
+    no_ramp_elapsed = timed_steps(step, args.steps, args.warmup, barrier, torch.cuda.synchronize, allreduce_max)
     t_ramp = time.perf_counter()
     ramp_steps = 0
     while time.perf_counter() - t_ramp < args.ramp_seconds:
@@ -382,8 +410,9 @@ def main():
     ev0.record()                                   # torch creates the HIP event handle at the first record(): not inside the timed region
     ev1.record()                                   # (two hipEventCreate calls cost ~25 us there -- 1 % of a 20-step run)
     elapsed = timed_steps(step_with_events, args.steps, 0, barrier, torch.cuda.synchronize, allreduce_max)
-    dev_ms = ev0.elapsed_time(ev1) / args.steps
-    dev_ms = allreduce_max(dev_ms)
+    own_dev_ms = ev0.elapsed_time(ev1) / args.steps
+    dev_ms = allreduce_max(own_dev_ms)
+    group = group_record(dist, torch, dev if args.backend == "nccl" else "cpu", world, args.backend, own_dev_ms)
 
     # per-step device-time distribution over K more steps (outside the timed region)
     step_ms = spread(device_times(step, args.steps, torch))
@@ -507,7 +536,11 @@ def main():
                      "note": "achieved = 4 B x coefficients this device writes per step / device time of one step (every kernel of the "
                              "step; HIP events on the launch stream around the K timed steps); spread = per-step event times of K "
                              "further steps; dtype = widest arithmetic type on the path (64-bit CORDIC state), output int32"},
-        "ramp": {"seconds": args.ramp_seconds, "steps": ramp_steps},
+        "ramp": {"seconds": args.ramp_seconds, "steps": ramp_steps,
+                 "no_ramp": {"ms_per_step": no_ramp_elapsed / args.steps * 1e3, "value": total / no_ramp_elapsed / 1e9,
+                             "note": "the same W warm-up + K timed steps run BEFORE the ramp (cold clocks); `value` above is after it"}},
+        "ranks_seen": group["ranks_seen"], "device_ms_per_step_by_rank": group["device_ms_per_step_by_rank"], "backend": group["backend"],
+        "scratch_bytes": int(workspace.numel()) if workspace is not None else 0,
         "parity_spot_check": parity,
         "cpp_model": cpp_leg,
         "extra_legs": legs,

@@ -64,11 +64,11 @@ def _write_stamp(target, digest):
 
 
 KERNEL_UNITS = ("bhw_direct.hip", "bhw_build.hip", "bhw_combine.hip", "bhw_fused.hip", "bhw_taylor.hip", "bhw_variants.hip")
-HEADERS = ("bhw_internal.h", "bhw_device.h", "bhw_tables.inc")
+HEADERS = ("bhw_internal.h", "bhw_plan.h", "bhw_device.h", "bhw_tables.inc")
 
 
 def library_sources():
-    srcs = [os.path.join(CSRC, f) for f in ("bhw_api.cpp", "bhw_rom.c") + KERNEL_UNITS + HEADERS]
+    srcs = [os.path.join(CSRC, f) for f in ("bhw_api.cpp", "bhw_plan.cpp", "bhw_rom.c") + KERNEL_UNITS + HEADERS]
     srcs.append(os.path.join(ROOT, "include", "bhw.h"))
     return srcs
 
@@ -89,8 +89,13 @@ def compile_units(objdir, flags=(), jobs=None, only=None):
         obj = os.path.join(objdir, os.path.splitext(unit)[0] + ".o")
         jobsl.append((obj, base + ["-x", "hip", "-c", os.path.join(CSRC, unit), "-o", obj]))
     rom_o = os.path.join(objdir, "bhw_rom.o")
+    plan_o = os.path.join(objdir, "bhw_plan.o")
     if not only:
         jobsl.append((rom_o, ["gcc", "-O2", "-fPIC", "-c", os.path.join(CSRC, "bhw_rom.c"), "-o", rom_o]))
+    if not only or "bhw_plan.cpp" in only:
+        # the planner is plain C++ by construction (no hip* include): built with g++, like the sanitizer test builds it
+        jobsl.append((plan_o, ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-c", os.path.join(CSRC, "bhw_plan.cpp"), "-o", plan_o]
+                      + [f for f in flags if f.startswith("-D")]))
     with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
         outs = list(ex.map(lambda j: _run(j[1]), jobsl))
     return [j[0] for j in jobsl], "\n".join(outs)

@@ -10,7 +10,7 @@ SIN_CORDIC, SIN_TAYLOR, SIN_TAYLOR_ALL = 0, 1, 2
 WIN_HAMMING, WIN_HANN, WIN_BH3, WIN_BH4, WIN_BH5, WIN_BH7 = 1, 2, 3, 4, 5, 7
 ALGO_AUTO, ALGO_DIRECT, ALGO_TABLE, ALGO_FUSED = 0, 1, 2, 3
 TABLE_BEST, TABLE_PLAIN, TABLE_DELTA16, TABLE_RESIDUAL, TABLE_NIBBLE = 0, 1, 2, 3, 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/bhw.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
@@ -19,7 +19,7 @@ ABI_SYMBOLS = (
     "bhw_workspace_bytes", "bhw_generate_batched_device", "bhw_sincos_device", "bhw_generate_to_host",
     "bhw_sincos_to_host", "bhw_release_device", "bhw_apply_device", "bhw_atan2_device", "bhw_atan2_to_host",
     "bhw_prepare_device", "bhw_part_segments", "bhw_generate_part_device", "bhw_describe_plan",
-    "bhw_coeffs_preset", "bhw_gather_parts_device",
+    "bhw_coeffs_preset", "bhw_gather_parts_device", "bhw_workspace_bytes_ex",
 )
 
 
@@ -97,6 +97,8 @@ def lib():
     L.bhw_generate_device_ex.argtypes = [P, ci, vp, u64, u64, i32p, ctypes.POINTER(BhwExec)]
     L.bhw_workspace_bytes.restype = u64
     L.bhw_workspace_bytes.argtypes = [P, u64, u64, u32]
+    L.bhw_workspace_bytes_ex.restype = u64
+    L.bhw_workspace_bytes_ex.argtypes = [P, u64, u64, ctypes.POINTER(BhwExec)]
     L.bhw_generate_batched_device.argtypes = [P, ci, vp, u32, i32p]
     L.bhw_sincos_device.argtypes = [P, ci, vp, u64, u64, i32p, i32p]
     L.bhw_generate_to_host.argtypes = [P, ci, u64, u64, i32p]

@@ -235,7 +235,14 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_shared(BhwBuildPl
 //     2^26 / 32 bits) runs the six rotations instead (wave-uniform branch).
 // Per pair of entries: 9 shared rotations of 10 instructions + ~25 for the two tails, instead of 9 + 2 x 6 rotations of 9.
 constexpr int kMirrorTail = 6;         // rotations of the table tail (D's row index has kMirrorTail bits, its column 32 - KS <= 6 bits)
-constexpr int kMirrorGpw = 64;         // own groups per workgroup
+// Workgroup shape.  gfx950 starts about one workgroup per 10 ns chip-wide whatever its size (tools/ubench_turnaround.hip,
+// profiles/r04_ubench_turnaround.txt: one round of 2 048 x 256 threads needs ~20 us before its last workgroup runs, 512 x 1 024
+// threads ~5 us), and this pass is ONE round of workgroups: with 256 threads the chip was still filling during the first half of the
+// 46 us pass.  So the workgroup is 1 024 threads (16 waves, two per CU: the same eight waves per SIMD) wherever the table gives
+// at least one workgroup per CU; every wave still walks 16 groups, so a workgroup owns THREADS / 4 groups.
+constexpr int mirror_gpw(int threads) { return threads / 4; }                       // own groups per workgroup
+constexpr int mirror_heads_max(int threads) { return mirror_gpw(threads) / 2 + 8; } // cells of one range (>= 128 entries each) + 3
+constexpr int mirror_heads_pad(int threads) { return (mirror_heads_max(threads) + 63) / 64 * 64; }   // head-chain lanes per range
 constexpr int kTailZ = 256;            // tail_p covers z_KS in (-kTailZ, kTailZ)
 
 struct TailD { int8_t v[64 * 64]; };
@@ -340,27 +347,30 @@ __device__ __forceinline__ void rot_narrow_block(uint32_t &x, uint32_t &y, int32
 #undef BHW_ROT_I
 }
 
-template <int NITER, int FMT>
-__global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPlan plan, void *__restrict__ table)
+template <int NITER, int FMT, int THREADS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8))) void k_table_build_mirror(BhwBuildPlan plan, void *__restrict__ table)
 {
     static_assert(FMT == 2 || FMT == 3, "residual / nibble entries");
     static_assert(NITER >= 21 && NITER <= 32, "narrow state: 32-bit words");
-    __shared__ int64_t gx[kGroupsPerWg];
-    __shared__ int64_t gy[kGroupsPerWg];
-    __shared__ int32_t gz[kGroupsPerWg];
-    __shared__ int32_t gk[kGroupsPerWg];
-    __shared__ uint32_t gflag[kGroupsPerWg];                    // bit 0: leaf 0 met z == 0 inside the shared prefix; bit 1: narrow state
+    static_assert(THREADS == 256 || THREADS == 512 || THREADS == 1024, "workgroup shapes");
+    constexpr uint32_t gpw = mirror_gpw(THREADS);               // own groups per workgroup
+    constexpr uint32_t kHeads = mirror_heads_max(THREADS), kHeadsPad = mirror_heads_pad(THREADS);
+    static_assert(gpw + 2 * kHeadsPad + 64 <= THREADS, "prefix lanes, two ranges of head chains, the tail-table wave");
+    __shared__ int64_t gx[gpw];
+    __shared__ int64_t gy[gpw];
+    __shared__ int32_t gz[gpw];
+    __shared__ int32_t gk[gpw];
+    __shared__ uint32_t gflag[gpw];                             // bit 0: leaf 0 met z == 0 inside the shared prefix; bit 1: narrow state
     __shared__ uint32_t lut_s[32];
     __shared__ uint8_t tail_p[2 * kTailZ];                      // z_KS + kTailZ -> decision pattern of the tail
     __shared__ __attribute__((aligned(16))) int8_t tail_d[64 * 64];
-    constexpr uint32_t kWorkMax = 512;               // images to run as chains of their own (expected ~40 per workgroup)
+    constexpr uint32_t kWorkMax = 8 * gpw;           // images to run as chains of their own (expected ~0.6 per group)
     __shared__ uint32_t work_n;
     __shared__ uint32_t work_u[kWorkMax];
     if (threadIdx.x < 32) lut_s[threadIdx.x] = plan.lut[threadIdx.x];
     constexpr int n_iter = NITER;
     constexpr int KS = NITER - kMirrorTail;                     // image state taken at this rotation
     const uint32_t s = plan.z_shl;
-    constexpr uint32_t gpw = kMirrorGpw;                        // own groups per workgroup
     const uint32_t group0 = blockIdx.x * gpw;
     const uint32_t E = plan.entries;
     const uint32_t n_groups = E >> 7;   // groups that run chains of their own
@@ -374,10 +384,10 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
             work_n = 1u;
         }
     }
-    // tail tables, by the fourth wave alone (the first three run the prefix and head chains below, and every workgroup starts
+    // tail tables, by the last wave alone (the first ones run the prefix and head chains below, and every workgroup starts
     // with this serial phase): D copied from its constant image, the pattern of every z_KS from the ROM words
-    if (threadIdx.x >= 192u) {
-        const uint32_t t3 = threadIdx.x - 192u;
+    if (threadIdx.x >= (uint32_t)THREADS - 64u) {
+        const uint32_t t3 = threadIdx.x - ((uint32_t)THREADS - 64u);
 #pragma unroll
         for (int q = 0; q < 4; ++q) reinterpret_cast<int4 *>(tail_d)[t3 + 64u * q] = reinterpret_cast<const int4 *>(kTailD.v)[t3 + 64u * q];
 #pragma unroll
@@ -396,8 +406,8 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
 
 
     // records {c, s, dc, ds} of the cells this workgroup stores into: w = 0 its own range, w = 1 the image range.  Heads
-    // lo .. lo + n, plus head lo - 1 for the table's last cell (see k_table_build_shared), by full chains of the second / third wave.
-    __shared__ int32_t hc[2][kHeadsMax], hs[2][kHeadsMax];
+    // lo .. lo + n, plus head lo - 1 for the table's last cell (see k_table_build_shared), by full chains of the lanes behind the prefix lanes.
+    __shared__ int32_t hc[2][kHeads], hs[2][kHeads];
     const uint32_t d = fmt_cell_log(plan.tab_dlog);
     const uint32_t cells_total = E >> d;
     uint32_t cell_lo[2] = {0u, 0u}, n_cell[2] = {0u, 0u}, r_lo[2] = {u_lo, 0u}, r_hi[2] = {u_hi, 0u};   // entry ranges [r_lo, r_hi)
@@ -412,10 +422,10 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
             cell_lo[w] = r_lo[w] >> d;
             n_cell[w] = ((r_hi[w] - 1u) >> d) - cell_lo[w] + 1u;
         }
-    {
-        const uint32_t w = (threadIdx.x >> 6) - 1u;                  // wave 1 -> own range, wave 2 -> image range
-        const uint32_t t = threadIdx.x & 63u;
-        if (w < 2u && n_cell[w] && t < n_cell[w] + 2u) {
+    if (threadIdx.x >= gpw && threadIdx.x < gpw + 2u * kHeadsPad) {
+        const uint32_t w = (threadIdx.x - gpw) / kHeadsPad;          // lanes [gpw, gpw + pad) -> own range, the next pad lanes -> image range
+        const uint32_t t = (threadIdx.x - gpw) % kHeadsPad;
+        if (n_cell[w] && t < n_cell[w] + 2u) {
             const int64_t cell = (t <= n_cell[w]) ? (int64_t)cell_lo[w] + t : (int64_t)cell_lo[w] - 1;
             if (cell >= 0 && cell < (int64_t)cells_total) {
                 int64_t x = plan.x0, y = plan.x0;
@@ -464,9 +474,9 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
     __syncthreads();
 
     // the records themselves, once per workgroup: the groups read them back with one ds_read_b128 each
-    __shared__ int4 hrec[2][kHeadsMax];
+    __shared__ int4 hrec[2][kHeads];
     {
-        const uint32_t w = threadIdx.x >> 6, t = threadIdx.x & 63u;
+        const uint32_t w = threadIdx.x / kHeadsPad, t = threadIdx.x % kHeadsPad;
         if (w < 2u && t < n_cell[w]) {
             const uint32_t cell = cell_lo[w] + t;
             int4 r;
@@ -508,7 +518,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
     else                { idx_a = lane >> 2;              idx_m = 16u; idx_i = E >> 2; }
     if (!plan.tab_split) { idx_a = lane; idx_m = 64u; idx_i = E; }  // natural layout (nibble tables): index u, image E - u
     const uint32_t fmask = (1u << d) - 1u;
-    for (uint32_t gi = wave; gi < gpw; gi += kBuildThreads / 64) {
+    for (uint32_t gi = wave; gi < gpw; gi += THREADS / 64) {
         const uint32_t g = __builtin_amdgcn_readfirstlane(group0 + gi);   // (kept in a vector register otherwise, and the cell arithmetic with it)
         if (g >= n_groups) break;
         const int k0 = __builtin_amdgcn_readfirstlane(gk[gi]);
@@ -617,7 +627,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_table_build_mirror(BhwBuildPl
     // every workgroup 1.5 us longer at the end of the kernel, where nothing else is left to overlap it) ----
     __syncthreads();
     const uint32_t n_work = work_n < kWorkMax ? work_n : kWorkMax;
-    for (uint32_t i = threadIdx.x; i < n_work; i += kBuildThreads) {
+    for (uint32_t i = threadIdx.x; i < n_work; i += THREADS) {
         const uint32_t um = E - work_u[i];
         int64_t xf = plan.x0, yf = plan.x0;
         int32_t zf = (int32_t)((um << s) - plan.lut[0]);
@@ -647,36 +657,7 @@ __global__ __launch_bounds__(kBlock) void k_table_build_plain(BhwCordicCfg cfg, 
 
 } // namespace
 
-// Packed (delta16) table format applies when the (c, s) drift across a 64-entry block fits int16 with margin:
-// 63 * 2 pi * 2^(W-2-PW) + noise < 2^15  <=>  W - PW <= 8  (25.4 k at W - PW = 8).  Amplitude is 2^(W-2) for every model.
-bool bhwk_packed_ok(const BhwCordicCfg &c)
-{
-    if (c.z_shr != 0 || c.phi_width < 8) return false;
-    return (int)c.dat_width - (int)c.phi_width <= 8;
-}
-
-// Residual format: largest d <= 9 for which the straight line between records 2^d entries apart stays within half an LSB of
-// the true curve: (2 pi 2^d / 2^PW)^2 / 8 * 2^(W-2) <= 0.5.  0 = not applicable (d = 6 is left to delta16).
-uint32_t bhwk_resid_dlog(const BhwCordicCfg &c)
-{
-    if (c.z_shr != 0 || c.phi_width < 20 || c.dat_width + c.out_shr > 34 || c.n_iter < 7) return 0;
-    const int amp_bits = (int)c.dat_width - 2;                       // |c|, |s| <= 2^(W-2) (+1)
-    const int twice_d = 2 * (int)c.phi_width - amp_bits - 4;         // 4.93 * 2^(2d - 2PW + W - 2) <= 0.5
-    int d = twice_d / 2;
-    if (d > 9) d = 9;
-    if (d <= (int)kPackLog) return 0;                                // a 64-leaf build group must sit inside one cell
-    if ((int)c.phi_width - 2 - d < 2) return 0;
-    return (uint32_t)d;
-}
-
-// octant mirror (k_table_build_mirror): residual / nibble entries, tables of 2^20 entries and more, and the
-// exact quarter turn 2 * lut[0] == E << z_shl the symmetry rests on (true for every model at z_shr == 0; checked, not assumed)
-bool bhwk_build_mirror_applies(const BhwCordicCfg &c, uint32_t entries)
-{
-    const int fmt = fmt_of(c.tab_dlog);
-    return (fmt == 2 || fmt == 3) && (c.tab_split || fmt == 3) && c.z_shr == 0 && entries >= (1u << 20) && c.n_iter >= 21 &&
-           c.dat_width + c.out_shr <= 34 && 2ull * (uint64_t)(uint32_t)c.lut[0] == ((uint64_t)entries << c.z_shl);
-}
+// (bhwk_packed_ok, bhwk_resid_dlog, bhwk_build_mirror_applies, bhwk_build_mirror_threads: bhw_plan.cpp)
 
 // One whole period of cordic() (bhwk_sincos): the shared-prefix chains of the table build with the four quadrant images written
 // straight out (k_table_build_shared<N, 4>).
@@ -758,14 +739,23 @@ int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c_in, int32_t *d_ta
         if (c.n_iter < 21 && fmt != 0) return (int)hipErrorInvalidValue;
         if (bhwk_build_mirror_applies(c, entries)) {
             const unsigned own_groups = entries >> 7;
-            const dim3 mgrid((own_groups + kMirrorGpw - 1) / kMirrorGpw);
-            plan.groups_per_wg = kMirrorGpw;
+            // 1 024-thread workgroups once they still give every CU two (tables of 2^24 entries and more), 256 below
+            const unsigned threads = bhwk_build_mirror_threads(entries);
+            const unsigned mgpw = (unsigned)mirror_gpw((int)threads);
+            const dim3 mgrid((own_groups + mgpw - 1) / mgpw), mblock(threads);
+            plan.groups_per_wg = mgpw;
             switch (c.n_iter) {
-#define BHW_CASE_M(N) case N: if (fmt == 2) BHW_LAUNCH((k_table_build_mirror<N, 2>), mgrid, block, 0, st, plan, (void *)d_table); \
-                              else          BHW_LAUNCH((k_table_build_mirror<N, 3>), mgrid, block, 0, st, plan, (void *)d_table); break;
+#if defined(BHW_MIRROR_THREADS) && BHW_MIRROR_THREADS == 512      /* A/B builds only (tools/ab_inproc.py) */
+#define BHW_CASE_MT(N, F) BHW_LAUNCH((k_table_build_mirror<N, F, 512>), mgrid, mblock, 0, st, plan, (void *)d_table)
+#else
+#define BHW_CASE_MT(N, F) do { if (threads == 1024u) BHW_LAUNCH((k_table_build_mirror<N, F, 1024>), mgrid, mblock, 0, st, plan, (void *)d_table); \
+                               else                  BHW_LAUNCH((k_table_build_mirror<N, F, 256>), mgrid, mblock, 0, st, plan, (void *)d_table); } while (0)
+#endif
+#define BHW_CASE_M(N) case N: if (fmt == 2) BHW_CASE_MT(N, 2); else BHW_CASE_MT(N, 3); break;
                 BHW_CASE_M(21) BHW_CASE_M(22) BHW_CASE_M(23) BHW_CASE_M(24) BHW_CASE_M(25) BHW_CASE_M(26) BHW_CASE_M(27) BHW_CASE_M(28)
                 BHW_CASE_M(29) BHW_CASE_M(30) BHW_CASE_M(31) BHW_CASE_M(32)
 #undef BHW_CASE_M
+#undef BHW_CASE_MT
             default: return (int)hipErrorInvalidValue;
             }
             return finish(hipSuccess);

@@ -84,16 +84,8 @@ __global__ __launch_bounds__(kBlock) void k_table_combine_fold(BhwCordicCfg cfg,
 // Tile shape (profiles/r01_ab_inproc.txt): 5 thread groups x 192 lanes.  Thread group p holds the three inv3-siblings of the
 // 15-run tile with i5 = p (24 sums per thread, ~52 VGPRs), so two 960-thread workgroups fit a CU and the gathers of one
 // overlap the arithmetic of the other: 0.1907 ms vs 0.1945 ms for 3 groups x 256 lanes (40 sums per thread, one workgroup per CU).
-constexpr int kTileThreads = 960;
-constexpr int kTileLanes = 192;     // tile width in lanes; the tile's 15 runs are split over kTileThreads / kTileLanes thread groups
-
-struct BhwTilePlan {
-    uint32_t offs[16];   // (i3*inv3 + i5*inv5) mod ring, index i3 + 3*i5; padded by repeating the last run
-    uint32_t n_tiles;    // tiles that cover the ring once
-    uint32_t tile0;      // first tile of this launch (interleaved ownership parts launch a sub-range of the tiles)
-    uint32_t img_mask;   // MASKED instances: bit 2j + h set = image (h, j), i.e. stream indices [(2j + h) N/8, +N/8), is wanted
-    uint32_t n0mod;      // MASKED instances: stream index (mod N) that `out` points at; image m lands at ((m N/8 - n0mod) mod N)
-};
+// (kTileThreads = 960, kTileLanes = 192 -- the tile's 15 runs are split over kTileThreads / kTileLanes thread groups -- and
+// BhwTilePlan: bhw_plan.h; the plan itself is made by bhwp_tile_plan, bhw_plan.cpp)
 
 // Quadrant fold for whole periods below the tile threshold, plain natural table: lane r in [0, N/4) owns n = r + j*N/4.  The
 // harmonic loop is unrolled (NTERMS) so the K-1 gathers issue together, and the arithmetic is that of the tile kernel
@@ -543,8 +535,7 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
 // All sums are plain int32: HLS rule modulo 2^32 as in the tile kernel; VHDL rule needs W + 2 <= 30 bits (z_shr > 0 means
 // W < PW <= 30 anyway; the launcher checks).
 // ---------------------------------------------------------------------------------------
-constexpr int kRlRun = 16;              // 8 or 16 (the swizzles below assume a multiple of 4 granule rows)
-constexpr int kRlBlock = 64;
+// kRlRun = 16 consecutive ring lanes per thread (8 or 16: the swizzles below assume a multiple of 4 granule rows), kRlBlock = 64: bhw_plan.h
 
 // LDS tile of one (wave, image): 1024 values as 256 granules of 16 bytes, granule index XOR-swizzled inside rows of eight
 // so that both the producer pattern (granule 4*lane + c) and the consumer pattern (granule 64*s + lane) are conflict-free.
@@ -698,54 +689,6 @@ int bhwk_table_combine_fold(const BhwLaunch &l, const BhwCordicCfg &c_in, const 
 }
 
 
-static uint32_t inv_mod_pow2(uint32_t a, uint32_t log2m)
-{
-    uint32_t x = a;                      // Newton iteration: x <- x (2 - a x), doubles the correct bits
-    for (int i = 0; i < 6; ++i) x *= 2u - a * x;
-    return log2m >= 32 ? x : (x & ((1u << log2m) - 1u));
-}
-
-bool bhwk_tile_applicable(const BhwCordicCfg &c, const BhwWinCfg &w)
-{
-    // With dropped phase bits (z_shr > 0) consecutive lanes share table entries, so the gathers are dense on their
-    // own: such tables take the one-run form of the kernel over the natural layout.
-    (void)w;
-    // below 2^22 coefficients a grid of 960-thread tiles leaves CUs idle; the one-lane-per-four fold kernel has many more,
-    // smaller workgroups and wins there (2^20: 15.0 vs 18.7 us, 2^21: 20.5 vs 21.2, 2^22: 36.0 vs 25.8; BH-7)
-    return c.phi_width >= 22 && c.phi_width <= 30;
-}
-
-// The tile plan of a configuration: run offsets on the ring [0, N/8), lanes per run and tile, tiles that cover the ring.
-static void make_tile_plan(const BhwCordicCfg &c, const BhwWinCfg &w, BhwTilePlan &tp, int &nb, uint32_t &lanes)
-{
-    const uint32_t lq = c.phi_width - 2, E = 1u << (lq - 1);   // the lane ring is [0, N/8): each lane owns r and r + N/8
-    const uint32_t inv3 = inv_mod_pow2(3, lq - 1), inv5 = inv_mod_pow2(5, lq - 1);
-    const int nb3 = (c.z_shr == 0 && w.n_terms > 3) ? 3 : 1, nb5 = (c.z_shr == 0 && w.n_terms > 5) ? 5 : 1;
-    nb = nb3 * nb5;
-    uint32_t sorted[15];
-    for (int i5 = 0; i5 < nb5; ++i5)
-        for (int i3 = 0; i3 < nb3; ++i3) {
-            const uint32_t o = (uint32_t)(((uint64_t)i3 * inv3 + (uint64_t)i5 * inv5) & (E - 1u));
-            // 3 thread groups: group p holds the five inv5-siblings of i3 = p (k = 5 dense per thread);
-            // 5 thread groups (kTileThreads = 5 * kTileLanes): group p holds the three inv3-siblings of i5 = p
-            if (kTileThreads / kTileLanes == 5 && nb == 15) tp.offs[i3 + nb3 * i5] = o;
-            else tp.offs[i5 + nb5 * i3] = o;
-            sorted[i3 + nb3 * i5] = o;
-        }
-    for (int i = nb; i < 16; ++i) tp.offs[i] = tp.offs[nb - 1];
-    // tiles needed so that every run class sweeps past the start of the next one around the ring
-    for (int i = 1; i < nb; ++i)
-        for (int j = i; j > 0 && sorted[j - 1] > sorted[j]; --j) { uint32_t t = sorted[j]; sorted[j] = sorted[j - 1]; sorted[j - 1] = t; }
-    uint64_t maxgap = 0;
-    for (int i = 0; i < nb; ++i) {
-        const uint64_t nxt = (i + 1 < nb) ? sorted[i + 1] : (uint64_t)sorted[0] + E;
-        if (nxt - sorted[i] > maxgap) maxgap = nxt - sorted[i];
-    }
-    lanes = (nb >= 15) ? (uint32_t)kTileLanes : (uint32_t)kTileThreads;
-    tp.n_tiles = (uint32_t)((maxgap + lanes - 1) / lanes);
-    tp.tile0 = 0;
-}
-
 // Tiles [tile0, tile0 + tile_count) of the plan (tile_count 0: all of them).
 int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c_in, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out,
                                   uint32_t tile0, uint32_t tile_count, uint32_t img_mask, uint32_t n0mod)
@@ -756,7 +699,7 @@ int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c_in, 
     BhwTilePlan tp;
     int nb;
     uint32_t lanes;
-    make_tile_plan(c, w, tp, nb, lanes);
+    bhwp_tile_plan(c, w, tp, nb, lanes);
     if (tile_count == 0) { tile0 = 0; tile_count = tp.n_tiles; }
     if (tile0 + tile_count > tp.n_tiles) return (int)hipErrorInvalidValue;
     tp.tile0 = tile0;
@@ -766,19 +709,7 @@ int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c_in, 
     if (masked && (nb != 15 || w.apply_x != nullptr || tp.img_mask == 0u)) return (int)hipErrorInvalidValue;
     const int mode = (w.combine != BHW_COMBINE_HLS) ? 2 : (c.ones_neg ? 1 : 0);
     const dim3 grid(tile_count), block(kTileThreads);
-    // one-instruction products (tile_harmonic FAST): HLS rule, 15-run tiles, every harmonic weight below 2^(W-3) in magnitude
-    // (the built-in weights are: a_k <= 0.49 * 2^(W-1 or W-2)); caller-scaled weights beyond that take the 64-bit products
-    bool fast = nb == 15 && c.dat_width >= 3;
-    for (uint32_t k = 1; k < w.n_terms && fast; ++k) {
-        const int64_t lim = (int64_t)1 << (c.dat_width - 3);
-        fast = (int64_t)w.aa[k] < lim && (int64_t)w.aa[k] > -lim;       // (> : the kernel also multiplies by the negated pre-shifted weight)
-    }
-    if (mode == 2 && fast) {
-        // VHDL rule, one-word sums: |sum of the terms| <= sum of (|a_k| + 1) must stay below 2^31 (the built-in weights: < 2^(W-1))
-        int64_t bound = 0;
-        for (uint32_t k = 0; k < w.n_terms; ++k) bound += (w.aa[k] < 0 ? -(int64_t)w.aa[k] : (int64_t)w.aa[k]) + 1;
-        fast = bound < ((int64_t)1 << 31);
-    }
+    const bool fast = bhwp_tile_fast(c, w, nb);                     // one-instruction products (and, VHDL rule, one-word sums)
 #define BHW_LAUNCH_TILE_MFK(NB, M, F, K)                                                                                 \
     do {                                                                                                                 \
         if (c.tab_dlog == 0)             BHW_LAUNCH((k_table_combine_tile<NB, M, 0, F, K>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
@@ -815,91 +746,6 @@ int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c_in, 
 int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out)
 {
     return bhwk_table_combine_tile_range(l, c, w, d_table, d_out, 0, 0, 0xFFu, 0u);
-}
-
-// A contiguous index range that is a whole number of eighths of the window (and less than all of it) can be produced by the
-// tile kernel as a subset of its eight images: `*img_mask` = the images, `*n0mod` = n0 mod N (see BhwTilePlan).
-bool bhwk_tile_images_applicable(const BhwCordicCfg &c, const BhwWinCfg &w, uint64_t n0, uint64_t count, uint32_t *img_mask, uint32_t *n0mod)
-{
-    if (!bhwk_tile_applicable(c, w) || c.z_shr != 0 || w.apply_x != nullptr || w.n_terms <= 5) return false;   // 15-run tiles only
-    const uint64_t N = 1ull << c.phi_width, eighth = N >> 3;
-    if (count == 0 || count >= N || (count % eighth) != 0 || (n0 % eighth) != 0) return false;
-    const uint32_t m0 = (uint32_t)((n0 % N) / eighth), n_img = (uint32_t)(count / eighth);
-    uint32_t mask = 0;
-    for (uint32_t i = 0; i < n_img; ++i) mask |= 1u << ((m0 + i) & 7u);
-    *img_mask = mask;
-    *n0mod = (uint32_t)(n0 % N);
-    return true;
-}
-
-// Kernel names of the table strategy's two passes for a resolved configuration (bhw_describe_plan: profilers, bench labels).
-// Mirrors the dispatch in bhwk_table_build / bhwk_table_combine_tile_range / bhwk_table_combine_fold.
-void bhwk_describe_table(const BhwCordicCfg &c_in, const BhwWinCfg &w, bool tiled, char *build, char *combine, size_t len)
-{
-    const BhwCordicCfg c = table_layout(c_in);
-    const uint32_t entries = 1u << (c.phi_width - 2 - c.z_shr);
-    const bool fits = (c.dat_width + c.out_shr <= 34);
-    const int fmt = fmt_of(c.tab_dlog);
-    if (fits && c.n_iter >= 7 && entries < (1u << 20) && c.tab_dlog == 0 && !c.tab_split) snprintf(build, len, "k_table_build_plain<%u>", c.n_iter);
-    else if (entries >= 64 && fits && c.n_iter >= 2)
-        snprintf(build, len, bhwk_build_mirror_applies(c, entries) ? "k_table_build_mirror<%u,%d>" : "k_table_build_shared<%u,%d>", c.n_iter, fmt);
-    else snprintf(build, len, "k_table_build<%s>", c.wide ? "int64_t" : "int32_t");
-    const int mode = (w.combine != BHW_COMBINE_HLS) ? 2 : (c.ones_neg ? 1 : 0);
-    if (tiled) {
-        const int nb3 = (c.z_shr == 0 && w.n_terms > 3) ? 3 : 1, nb5 = (c.z_shr == 0 && w.n_terms > 5) ? 5 : 1;
-        snprintf(combine, len, "k_table_combine_tile<%d,%d,%d>", nb3 * nb5, mode, fmt);
-    } else if (c.tab_dlog == 0 && !c.tab_split) snprintf(combine, len, "k_table_combine_fold_t<%u,%d>", w.n_terms, mode);
-    else snprintf(combine, len, "k_table_combine_fold");
-}
-
-// Interleaved ownership (bhw_generate_part_device): the ring lanes of part `part` of `n_parts`, as runs of consecutive r.
-// Where the tile kernel applies the parts are contiguous ranges of its tiles, i.e. the plan's sibling runs (so a part can be
-// produced by the tile kernel over the full table or by the fused kernel, with the same ownership); elsewhere they are
-// contiguous ranges of the ring in 64-lane units.  Runs that wrap the ring are split; neighbouring parts overlap by the few
-// lanes the tile plan covers twice at its seams (identical values).
-int bhwk_part_runs(const BhwCordicCfg &c, const BhwWinCfg &w, uint32_t part, uint32_t n_parts, BhwFoldRun *runs, uint32_t *tile0, uint32_t *tile_count)
-{
-    const uint32_t H = 1u << (c.phi_width - 3);
-    *tile0 = *tile_count = 0;
-    if (n_parts < 1) n_parts = 1;
-    if (!bhwk_tile_applicable(c, w)) {
-        const uint32_t units = (H + 63u) >> 6;
-        const uint32_t a = (uint32_t)((uint64_t)units * part / n_parts) << 6, b = (uint32_t)((uint64_t)units * (part + 1u) / n_parts) << 6;
-        runs[0] = BhwFoldRun{a < H ? a : H, b < H ? b : H};
-        return runs[0].r_end > runs[0].r0 ? 1 : 0;
-    }
-    BhwTilePlan tp;
-    int nb;
-    uint32_t lanes;
-    make_tile_plan(c, w, tp, nb, lanes);
-    const uint32_t t0 = (uint32_t)((uint64_t)tp.n_tiles * part / n_parts), t1 = (uint32_t)((uint64_t)tp.n_tiles * (part + 1u) / n_parts);
-    *tile0 = t0;
-    *tile_count = t1 - t0;
-    if (t1 == t0) return 0;
-    const uint64_t len = (uint64_t)(t1 - t0) * lanes;
-    int n = 0;
-    for (int b = 0; b < nb; ++b) {
-        if (len >= H) { runs[0] = BhwFoldRun{0u, H}; return 1; }
-        const uint32_t start = (uint32_t)(((uint64_t)t0 * lanes + tp.offs[b]) & (H - 1u));
-        if (start + len <= H) runs[n++] = BhwFoldRun{start, (uint32_t)(start + len)};
-        else {
-            runs[n++] = BhwFoldRun{start, H};
-            runs[n++] = BhwFoldRun{0u, (uint32_t)(start + len - H)};
-        }
-    }
-    return n;
-}
-
-// Run-length kernel: z_shr > 0, at most one entry step per harmonic inside a 16-lane run, ring a multiple of the workgroup's
-// 2048 lanes, plain natural table, 16-byte aligned output, no fused apply; VHDL rule in int32 needs W + 2 <= 30.
-bool bhwk_runlength_applicable(const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_out)
-{
-    if (c.z_shr == 0 || c.tab_dlog != 0 || c.tab_split != 0 || w.apply_x != nullptr) return false;
-    if (c.phi_width < 15 || c.phi_width > 30) return false;                       // ring (2^(PW-3)) >= 2048 lanes
-    if (((w.n_terms - 1u) * (uint32_t)kRlRun) > (1u << c.z_shr)) return false;
-    if (c.phi_width - 2u - c.z_shr < 2u) return false;                            // H a multiple of 2^z_shr
-    if (w.combine != BHW_COMBINE_HLS && c.dat_width > 28) return false;
-    return (((uintptr_t)d_out) & 15u) == 0;                                       // (NULL: the caller asks about the configuration only)
 }
 
 int bhwk_runlength_window(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out)

@@ -8,7 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <type_traits>
-#include "bhw_internal.h"
+#include "bhw_plan.h"
 
 namespace {
 
@@ -105,10 +105,7 @@ __device__ __forceinline__ uint32_t tab_index(uint32_t u, uint32_t log2_entries,
 //          oracle); like the other packed formats it is used only after the build kernel has checked every entry of the
 //          configuration (a model whose noise is wider -- the cpp model reaches 10 -- falls back to the byte fields).
 // The combine pass is bound by table + output traffic as much as by arithmetic, and these cut the table's share to 1/2 .. 1/8.
-constexpr uint32_t kPackLog = 6;
-constexpr uint32_t kNibbleFlag = 16;            // cfg.tab_dlog = kNibbleFlag + d
-__host__ __device__ constexpr uint32_t fmt_cell_log(uint32_t tab_dlog) { return tab_dlog & (kNibbleFlag - 1u); }
-__host__ __device__ constexpr int fmt_of(uint32_t tab_dlog) { return tab_dlog == 0 ? 0 : tab_dlog == kPackLog ? 1 : tab_dlog >= kNibbleFlag ? 3 : 2; }
+// (kPackLog, kNibbleFlag, fmt_cell_log(), fmt_of(), table_layout(): bhw_plan.h, shared with the HIP-free planner)
 
 __device__ __forceinline__ int2 tab_predict(const int4 rec, uint32_t f, uint32_t d)
 {
@@ -642,14 +639,6 @@ __device__ __forceinline__ void rot_step_dyn(int64_t &x, int64_t &y, int32_t &z,
     y += (int64_t)sg * (int64_t)xs;
     if (mad24) z += __mul24(nsg, (int32_t)lutk);
     else       z = (int32_t)((uint32_t)z - lutk + ((2u * lutk) & (uint32_t)m));
-}
-
-// The layout goes with the format: nibble tables are always in the natural order (resid_offset), whatever the caller asked for.
-inline BhwCordicCfg table_layout(const BhwCordicCfg &c)
-{
-    BhwCordicCfg n = c;
-    if (fmt_of(c.tab_dlog) == 3) n.tab_split = 0u;
-    return n;
 }
 
 inline unsigned grid_for(uint64_t count) { return (unsigned)((count + kBlock - 1) / kBlock); }

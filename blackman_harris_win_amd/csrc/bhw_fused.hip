@@ -23,8 +23,7 @@ namespace {
 // The lanes of a launch are a list of runs of consecutive r (one run for a whole window; the 15 sibling runs of the tile plan,
 // split where they wrap, for an ownership part).
 // ---------------------------------------------------------------------------------------
-constexpr int kFoldRunsMax = 32;
-constexpr int kFoldBlock = 256;
+// (kFoldRunsMax = 32, kFoldBlock = 256: bhw_plan.h)
 
 struct BhwFoldPlan {
     uint32_t lut[34];                        // rescaled ROM as 32-bit words (quarter circle <= 2^32); [32], [33] = 0: the loop reads one ahead
@@ -596,12 +595,6 @@ __global__ __launch_bounds__(256) void k_fold_split(BhwWinCfg win, BhwFoldPlan p
 
 } // namespace
 
-bool bhwk_fold_direct_applicable(const BhwCordicCfg &c)
-{
-    // rot_step's forms: |x| < 2^33 and a quarter circle <= 2^32; ring of at least one wave
-    return c.dat_width + c.out_shr <= 34 && c.phi_width >= 9 && c.phi_width <= 30 && c.n_iter >= 2;
-}
-
 int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const BhwFoldRun *runs, uint32_t n_runs, int32_t *d_out)
 {
     if (!n_runs) return 0;
@@ -643,26 +636,10 @@ int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg 
     if (!wg) return 0;
     const int mode = (w.combine != BHW_COMBINE_HLS) ? 2 : (c.ones_neg ? 1 : 0);
     const dim3 grid(wg), blk(block);
-    // fewer than ~4 waves per SIMD in the whole launch: latency-bound, walk the chains in lockstep
-    const bool lockstep = total <= (1u << 18);
-    // on 32-bit state with in-wave prefixes when x, y (|.| < 2^(W + out_shr - 1)) and z (the quarter circle) fit signed words -- at
-    // every launch size: where the chip is full the form still wins a little over the 64-bit one with its own split level per chain
-    // (BH-4 2^22 / 24-bit 16.1 -> 15.2 us, BH-5 17.7 -> 17.4)
-    const bool narrow = c.dat_width + c.out_shr <= 30u && c.phi_width - 2u - c.z_shr + c.z_shl <= 30u;
-    {
-        // |x|, |y| < 2^B, B = W + out_shr - 1: (x >> k) fits 24 signed bits from k = B - 23 on; the ROM word from the first lut[k] < 2^23 on
-        const int B = (int)(c.dat_width + c.out_shr) - 1;
-        uint32_t k24 = B > 23 ? (uint32_t)(B - 23) : 1u;
-        while (k24 < c.n_iter && (uint32_t)c.lut[k24] >= (1u << 23)) ++k24;
-        plan.k24 = k24;
-    }
-    // short launches, form of the kernel: 2 = chains split over four waves per 64 lanes (k_fold_split), 1 = lockstep, 0 = sequential
-    // measured per call (profiles/r02_ab_fused_lockstep.txt): split 7.8 / lockstep 9.0 us at 2^13 lanes (BH-7 2^16), 6.9 / 7.7 at
-    // 2^15 (BH-5 2^18), 9.7 / 9.7 at 2^16, 9.0 / 8.2 at 2^17 (BH-4 2^20): split up to 2^15 lanes, lockstep up to 2^18
-    // (round 3, tools/bench_short_graph.py: where the narrow form applies it beats the split one at every size for windows of up to
-    // five terms -- 4.4 / 4.5 / 4.8 against 5.1 / 5.2 / 5.5 us at 2^14 / 2^16 / 2^18 points of BH-4 -- and loses to it with the nine
-    // chains of a 7-term window, 6.8 against 6.6 us at 2^16)
-    const bool split = total <= (1u << 15) && !(narrow && w.n_terms <= 5);
+    // form of the kernel for this many lanes (bhwp_fold_form, bhw_plan.cpp: the measurements behind the thresholds are quoted there)
+    const int form = bhwp_fold_form(c, w, total);
+    const bool split = form == BHWP_FOLD_SPLIT, narrow = form == BHWP_FOLD_NARROW, lockstep = form == BHWP_FOLD_LOCKSTEP;
+    plan.k24 = bhwp_fold_k24(c);
     dim3 grid_s(0), blk_s(256);
     if (split) {
         uint32_t wgs = 0;

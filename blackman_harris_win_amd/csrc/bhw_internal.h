@@ -81,6 +81,7 @@ int bhwk_table_combine(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCf
                        uint64_t n0, uint64_t count, int32_t *d_out);
 // whole-period cordic() sweep through the shared-prefix chains of the table build (bhwk_sincos picks it for periods >= 2^16)
 int bhwk_sincos_sweep(const BhwLaunch &l, const BhwCordicCfg &c, uint64_t theta0, int32_t *d_sin, int32_t *d_cos);
+// Predicates and shapes below that take no BhwLaunch are host arithmetic only and live in the HIP-free bhw_plan.cpp.
 // the octant-mirror build kernel applies to this table (bhw_build.hip; bhwk_describe_table names the kernel)
 bool bhwk_build_mirror_applies(const BhwCordicCfg &c, uint32_t entries);
 // which packed table formats a configuration admits (delta16; residual cell size, 0 = not applicable)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BHW_ABI_VERSION 3u   /* 3: bhw_coeffs_preset, bhw_gather_parts_device added (nothing removed or changed) */
+#define BHW_ABI_VERSION 4u   /* 3: bhw_coeffs_preset, bhw_gather_parts_device; 4: bhw_workspace_bytes_ex (nothing removed or changed) */
 
 /* CORDIC bit-model (the reference holds three that are not bit-identical). */
 enum {
@@ -155,8 +155,14 @@ int bhw_generate_device(const bhw_params *p, int device, void *hip_stream,
                         uint64_t n0, uint64_t count, int32_t *d_out);
 int bhw_generate_device_ex(const bhw_params *p, int device, void *hip_stream,
                            uint64_t n0, uint64_t count, int32_t *d_out, const bhw_exec *ex);
-/* Device scratch the given call would need with `algo` (0 for the direct strategy). */
+/* Device scratch that is enough for the given call with `algo` whatever table format it ends up using (0 for the direct and
+ * fused strategies): 8 bytes per first-quadrant table entry.  An upper bound that never changes for a configuration. */
 uint64_t bhw_workspace_bytes(const bhw_params *p, uint64_t n0, uint64_t count, uint32_t algo);
+/* The same for the call as `ex` describes it (algo, table_format), counting the table format(s) the call would use right now:
+ * after bhw_prepare_device (or a first call) has settled the packed formats of the configuration this is the size of the one
+ * format in use -- 16.5 MiB instead of 128 MiB for a 2^26-point window at 32 bits -- and it never grows afterwards.  A
+ * workspace of at least this size is accepted by the call; the library-owned scratch of a stream is sized by the same rule. */
+uint64_t bhw_workspace_bytes_ex(const bhw_params *p, uint64_t n0, uint64_t count, const bhw_exec *ex);
 
 /* What bhw_generate_device_ex(p, ..., n0, count, ..., ex) would launch right now, as one line of text into buf (NUL-terminated,
  * truncated to len): strategy, table format and the kernel names a profiler will show.  The table format of a configuration
@@ -167,9 +173,12 @@ int bhw_describe_plan(const bhw_params *p, uint64_t n0, uint64_t count, const bh
  * (taylor_sincos.vhd:91-111 builds it at elaboration), allocates the library-owned table scratch of this stream, and verifies
  * once, on the device, that the packed table formats are exact for this (model, phi_width, dat_width, precision) -- a property
  * of the configuration, not of the weights.  Synchronous.  After it, bhw_generate_* / bhw_apply_* / bhw_sincos_* calls with
- * these widths neither allocate nor synchronise, so they can be captured into a HIP graph.  Without it the first call does
- * the same work inline (one synchronisation); during stream capture an unprepared Taylor call fails with BHW_ERR_HIP and an
- * unprepared table call uses the plain table format. */
+ * these widths on this stream neither allocate nor synchronise, so they can be captured into a HIP graph -- whole periods,
+ * partial ranges and explicit bhw_exec.algo alike (the scratch is reserved also for configurations whose whole periods take the
+ * table-free fused kernel).  One exception: a range WITHOUT a whole period of a window whose plain table exceeds 64 MiB
+ * (phi_width >= 26 at z_shr = 0) grows the scratch on its first use; pass bhw_exec.workspace for such calls inside a capture.
+ * Without prepare the first call does the same work inline (one synchronisation); during stream capture an unprepared Taylor
+ * call fails with BHW_ERR_HIP and an unprepared table call uses the plain table format. */
 int bhw_prepare_device(const bhw_params *p, int device, void *hip_stream);
 
 /* Interleaved ownership of ONE window over several devices (every coefficient is an independent function of its

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_loads_and_exports_every_declared_symbol():
     L = B.lib()
-    assert L.bhw_abi_version() == 3
+    assert L.bhw_abi_version() == 4
     header = open(os.path.join(ROOT, "include", "bhw.h")).read()
     declared = set(re.findall(r"\b(bhw_[a-z_0-9]+)\s*\(", header))
     assert declared == set(B.ABI_SYMBOLS)
@@ -155,7 +155,7 @@ def test_headline_kernels_have_no_scratch():
         _build.build_library(force=True)
     with open(_build.RESOURCES) as f:
         res = json.load(f)
-    headline = ["k_table_build_mirror<32, 3>", "k_table_build_mirror<32, 2>", "k_table_build_mirror<31, 3>", "k_table_combine_tile<15, 2, 3, true, false>", "k_table_combine_tile<15, 0, 3, true, false>",
+    headline = ["k_table_build_mirror<32, 3, 1024>", "k_table_build_mirror<32, 2, 1024>", "k_table_build_mirror<31, 3, 1024>", "k_table_build_mirror<32, 3, 256>", "k_table_combine_tile<15, 2, 3, true, false>", "k_table_combine_tile<15, 0, 3, true, false>",
                 "k_table_combine_tile<15, 0, 2, true, false>", "k_table_combine_tile<15, 1, 2, true, false>", "k_table_combine_tile<15, 0, 2, false, false>",
                 "k_fold_direct<7, 0, 0>", "k_fold_direct<4, 0, 2>", "k_fold_direct<4, 0, 1>", "k_fold_split<4, 0>", "k_runlength_window<7, 1, true>"]
     for name in headline:
@@ -164,6 +164,8 @@ def test_headline_kernels_have_no_scratch():
         assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0, (name, r)
     for name in ("k_table_combine_tile<15, 0, 3, true, false>", "k_table_combine_tile<15, 0, 2, true, false>"):
         assert res[name]["VGPRs"] <= 64 and res[name]["LDS Size"] <= 80 * 1024, (name, res[name])   # two 960-thread workgroups per CU
+    for name in ("k_table_build_mirror<32, 3, 1024>", "k_table_build_mirror<32, 2, 1024>"):
+        assert res[name]["VGPRs"] <= 64 and res[name]["LDS Size"] <= 80 * 1024, (name, res[name])   # two 1 024-thread workgroups per CU
 
 
 def test_coefficient_presets():
@@ -203,6 +205,54 @@ def test_describe_plan_names_the_run_length_kernel():
     assert B.describe_plan(p, 0, 1 << 22).startswith("table")
     p = B.make_params(4, 12, 8, model=B.MODEL_CPP)
     assert B.describe_plan(p, 0, 1 << 12).startswith("fused")
+
+
+def test_describe_plan_names_the_fused_kernel_that_runs():
+    """The fused strategy starts one of four kernels (k_fold_split or k_fold_direct<.., FORM>) depending on the launch size and
+    the state width; the plan line names that one (round-3 advisor finding: it used to print a two-parameter k_fold_direct)."""
+    from blackman_harris_win_amd import binding as B
+    assert "k_fold_direct<4,0,2>" in B.describe_plan(B.make_params(4, 20, 24), 0, 1 << 20)        # C2: 32-bit-state form
+    assert "k_fold_split<7,0>" in B.describe_plan(B.make_params(7, 16, 32), 0, 1 << 16)           # 2^13 lanes, 64-bit state, 9 chains
+    assert "k_fold_direct<7,0,1>" in B.describe_plan(B.make_params(7, 19, 32), 0, 1 << 19)        # 2^16 lanes: lockstep
+    assert "k_fold_direct<4,2,2>" in B.describe_plan(B.make_params(4, 16, 24, combine=B.COMBINE_VHDL), 0, 1 << 16)
+    # dropped phase bits but too few coefficients per table entry for the run-length kernel (z_shr 1: 2 < 3 x 16): the table
+    # strategy would fall to build + quadrant fold, so AUTO keeps the fused kernel (round-3 advisor finding)
+    p = B.make_params(4, 20, 20, model=B.MODEL_CPP)
+    assert B.describe_plan(p, 0, 1 << 20).startswith("fused"), B.describe_plan(p, 0, 1 << 20)
+    assert "16-byte aligned output" in B.describe_plan(B.make_params(7, 26, 16, model=B.MODEL_CPP), 0, 1 << 26)
+
+
+def test_workspace_bytes_ex_is_tight_and_bounded():
+    """bhw_workspace_bytes is the format-independent upper bound (8 bytes per entry); bhw_workspace_bytes_ex counts the format(s)
+    the call would use now: the widest candidate while the packed formats are unverified, the one in use afterwards."""
+    import ctypes
+    from blackman_harris_win_amd import binding as B
+    L = B.lib()
+    L.bhw_dbg_table_format_verdict.argtypes = [ctypes.POINTER(B.BhwParams), ctypes.c_uint32, ctypes.c_int]
+    p = B.make_params(7, 25, 31)                                    # a configuration no other CPU test settles
+    E = 1 << 23
+    ex = B.BhwExec()
+    ex.struct_size = ctypes.sizeof(B.BhwExec)
+    ex.algo = B.ALGO_TABLE
+    bound = L.bhw_workspace_bytes(ctypes.byref(p), 0, 1 << 25, B.ALGO_TABLE)
+    assert bound == E * 8
+    assert L.bhw_workspace_bytes_ex(ctypes.byref(p), 0, 1 << 25, ctypes.byref(ex)) == bound      # unverified: may fall back to plain
+    L.bhw_dbg_table_format_info.argtypes = [ctypes.POINTER(B.BhwParams), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+    dl = ctypes.c_uint32(0)
+    L.bhw_dbg_table_format_info(ctypes.byref(p), ctypes.byref(dl), None)
+    d = dl.value
+    assert 7 <= d <= 9
+    assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), 16 + d, 1) == 1                      # nibble verified exact
+    tight = L.bhw_workspace_bytes_ex(ctypes.byref(p), 0, 1 << 25, ctypes.byref(ex))
+    assert E + (E >> d) * 16 <= tight <= E + (E >> d) * 16 + 1024
+    assert L.bhw_workspace_bytes_ex(ctypes.byref(p), 0, 1 << 24, ctypes.byref(ex)) == tight      # whole eighths of the window: the tile kernel over those images
+    assert L.bhw_workspace_bytes_ex(ctypes.byref(p), 5, 1 << 24, ctypes.byref(ex)) == bound      # a ragged range: general gather over the plain table
+    ex.table_format = B.TABLE_PLAIN
+    assert L.bhw_workspace_bytes_ex(ctypes.byref(p), 0, 1 << 25, ctypes.byref(ex)) == bound
+    ex.table_format = B.TABLE_BEST
+    ex.algo = B.ALGO_DIRECT
+    assert L.bhw_workspace_bytes_ex(ctypes.byref(p), 0, 1 << 25, ctypes.byref(ex)) == 0
+    L.bhw_dbg_table_format_verdict(ctypes.byref(p), 16 + d, 3)                                   # back to "unknown"
 
 
 def test_part_segments_and_generate_part_agree_on_applicability():

@@ -107,6 +107,9 @@ def test_bench_launches_its_own_ranks():
     assert rec["launch_check"] and rec["n_gpus"] == 2 and rec["steps"] == 5
     assert rec["ms_per_step"] >= 0.9 * 2 * 2.0                   # the slower rank's time (rank 1 sleeps 4 ms per step)
     assert rec["shard_of_last_rank"] == [1 << 26, 1 << 26]
+    # the record checks itself: the process group saw both ranks, and every rank's own time is in it (rank r sleeps 2 (r + 1) ms)
+    assert rec["ranks_seen"] == 2 and rec["backend"] == "gloo"
+    assert rec["device_ms_per_step_by_rank"] == [2.0, 4.0]
 
 
 def test_bench_refuses_mismatched_world():
@@ -130,3 +133,6 @@ def test_bench_strong_scaling_two_ranks_share_one_gpu():
     rec = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["parity_spot_check"] is True
     assert rec["value"] > 0
+    assert rec["ranks_seen"] == 2 and rec["backend"] == "gloo" and len(rec["device_ms_per_step_by_rank"]) == 2
+    assert max(rec["device_ms_per_step_by_rank"]) == pytest.approx(rec["roofline"]["device_ms_per_step"])
+    assert rec["ramp"]["no_ramp"]["ms_per_step"] > 0

@@ -118,6 +118,56 @@ def test_prepare_then_graph_capture_without_workspace(torch):
             assert np.array_equal(out_y.cpu().numpy(), O.generate_mt(O.from_bhw(py), 777, 1 << 15))
 
 
+def test_prepare_covers_table_calls_of_fused_size_windows(torch):
+    """Round-3 advisor finding: bhw_prepare_device skipped the scratch when AUTO sends the WHOLE period to the fused kernel, yet a
+    partial range of such a window (no whole period -> table strategy) or an explicit BHW_ALGO_TABLE still builds a table; inside
+    a stream capture those calls then failed in the allocator.  After prepare both capture and replay bit-exactly."""
+    import blackman_harris_win_amd as bhw
+    st = torch.cuda.Stream()
+    p = B.make_params(4, 20, 23)                                   # BH-4 2^20: AUTO = fused for whole periods
+    n = 1 << 20
+    assert B.describe_plan(p, 0, n).startswith("fused") and B.describe_plan(p, 0, n // 2).startswith("table")
+    want = O.generate_mt(O.from_bhw(p), 0, n)
+    with torch.cuda.stream(st):
+        half = torch.zeros(n // 2, dtype=torch.int32, device="cuda")
+        whole = torch.zeros(n, dtype=torch.int32, device="cuda")
+        bhw.prepare(p)
+        st.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st):
+            bhw.generate(p, n // 4, n // 2, out=half)                        # partial range: table strategy, library scratch
+            bhw.generate(p, 0, n, out=whole, algo=B.ALGO_TABLE)              # explicit table strategy, no workspace
+        for _ in range(2):
+            half.zero_()
+            whole.zero_()
+            graph.replay()
+            st.synchronize()
+            assert np.array_equal(half.cpu().numpy(), want[n // 4:3 * n // 4])
+            assert np.array_equal(whole.cpu().numpy(), want)
+
+
+def test_library_scratch_is_sized_by_the_format_in_use(torch):
+    """The library-owned scratch of a stream holds the table format the configuration actually uses (16.5 MiB for the 2^26 / 32-bit
+    window with nibble entries), not the 8-bytes-per-entry bound; a caller's workspace of bhw_workspace_bytes_ex bytes is accepted."""
+    import blackman_harris_win_amd as bhw
+    p = B.make_params(7, 24, 32)
+    n = 1 << 24
+    bhw.prepare(p)                                                   # settles the packed formats of (HLS, 24, 32)
+    ex = B.BhwExec()
+    ex.struct_size = ctypes.sizeof(B.BhwExec)
+    ex.algo = B.ALGO_TABLE
+    tight = B.lib().bhw_workspace_bytes_ex(ctypes.byref(p), 0, n, ctypes.byref(ex))
+    bound = B.lib().bhw_workspace_bytes(ctypes.byref(p), 0, n, B.ALGO_TABLE)
+    assert "nibble" in B.describe_plan(p, 0, n, algo=B.ALGO_TABLE) and tight < bound // 7
+    ws = torch.empty(tight, dtype=torch.uint8, device="cuda")
+    out = bhw.generate(p, 0, n, algo=B.ALGO_TABLE, workspace=ws)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), O.generate_mt(O.from_bhw(p), 0, n))
+    with pytest.raises(B.BhwError) as ei:
+        bhw.generate(p, 0, n, algo=B.ALGO_TABLE, workspace=ws[:tight - 256])
+    assert ei.value.code == -4
+
+
 def _dbg():
     L = B.lib()
     P = ctypes.POINTER(B.BhwParams)
