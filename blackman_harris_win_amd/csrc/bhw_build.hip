@@ -245,12 +245,13 @@ constexpr int mirror_heads_max(int threads) { return mirror_gpw(threads) / 2 + 8
 constexpr int mirror_heads_pad(int threads) { return (mirror_heads_max(threads) + 63) / 64 * 64; }   // head-chain lanes per range
 constexpr int kTailZ = 256;            // tail_p covers z_KS in (-kTailZ, kTailZ)
 
-struct TailD { int8_t v[64 * 64]; };
+constexpr int kTailRows = 65;          // x >> KS of a biased-narrow group reaches 64 (x up to 2^NITER (1 + eps)); 64 + 32 + .. + 2 = 126 fits the byte
+struct TailD { int8_t v[kTailRows * 64 + 16]; };
 constexpr TailD make_tail_d()
 {
     TailD t{};
     for (int p = 0; p < 64; ++p)
-        for (int v = 0; v < 64; ++v) {
+        for (int v = 0; v < kTailRows; ++v) {
             int d = 0;
             for (int j = 0; j < kMirrorTail; ++j) d += ((p >> j) & 1) ? -(v >> j) : (v >> j);   // bit j set: z < 0 at rotation KS + j
             // stored [v][p]: the 64 leaves of a group share x >> KS and y >> KS (they differ by less than 2^18), so a wave reads one
@@ -307,14 +308,20 @@ __device__ __forceinline__ void rot_narrow(uint32_t &x, uint32_t &y, int32_t &z,
 // The last ten narrow rotations before the hand-over, KA = KS - 10 .. KS - 1, as ONE statement: entry at rotation KA + e (e <= 0: from the
 // top; the group's split rotation usually lies one or two rotations into the block), no scalar guard and no hazard no-op
 // between the rotations (the compiler separates adjacent asm statements that end / begin with EXEC accesses by an s_nop).
-template <int KA>
+// HI: the biased narrow state -- the word holds x - B, B = 2^(NITER-1), for groups whose x reaches 2^NITER (the first third of a
+// degree of the octant; every x_k then lies in [B, B + 2^32)).  B is a multiple of 2^k, so x >> k = ((x - B) >> k) + (B >> k)
+// exactly: one more VOP2 per rotation (a literal operand), everything else is the same code.  (Those 0.7 % of the groups all sit
+// in the first four workgroups; on the 64-bit path they kept the whole pass waiting 6 us for those four,
+// profiles/r04_build_timeline.txt.)
+template <int KA, int NITER, bool HI>
 __device__ __forceinline__ void rot_narrow_block(uint32_t &x, uint32_t &y, int32_t &z, uint32_t &zacc, const uint32_t *lut, int e)
 {
     uint32_t a, b;
-#define BHW_ROT_I(i)                                                                                                   \
+#define BHW_ROT_I(i, HI_ADD)                                                                                           \
     #i ":\n\t"                                                                                                          \
     "v_lshrrev_b32 %[a], %[k" #i "], %[y]\n\t"                                                                          \
     "v_lshrrev_b32 %[b], %[k" #i "], %[x]\n\t"                                                                          \
+    HI_ADD                                                                                                             \
     "v_min_u32 %[za], %[za], %[z]\n\t"                                                                                  \
     "v_cmpx_gt_i32 vcc, 0, %[z]\n\t"                                                                                    \
     "v_add_u32 %[x], %[x], %[a]\n\t"                                                                                    \
@@ -325,34 +332,91 @@ __device__ __forceinline__ void rot_narrow_block(uint32_t &x, uint32_t &y, int32
     "v_add_u32 %[y], %[y], %[b]\n\t"                                                                                    \
     "v_sub_u32 %[z], %[z], %[l" #i "]\n\t"                                                                              \
     "s_mov_b64 exec, -1\n"
-    asm volatile("s_cmp_lt_i32 %[e], 1\n\ts_cbranch_scc1 0f\n\t"
-                 "s_cmp_eq_u32 %[e], 1\n\ts_cbranch_scc1 1f\n\t"
-                 "s_cmp_eq_u32 %[e], 2\n\ts_cbranch_scc1 2f\n\t"
-                 "s_cmp_eq_u32 %[e], 3\n\ts_cbranch_scc1 3f\n\t"
-                 "s_cmp_eq_u32 %[e], 4\n\ts_cbranch_scc1 4f\n\t"
-                 "s_cmp_eq_u32 %[e], 5\n\ts_cbranch_scc1 5f\n\t"
-                 "s_cmp_eq_u32 %[e], 6\n\ts_cbranch_scc1 6f\n\t"
-                 "s_cmp_eq_u32 %[e], 7\n\ts_cbranch_scc1 7f\n\t"
-                 "s_cmp_eq_u32 %[e], 8\n\ts_cbranch_scc1 8f\n\t"
-                 "s_cmp_eq_u32 %[e], 9\n\ts_cbranch_scc1 9f\n\t"
+#define BHW_ROT_PLAIN(i) BHW_ROT_I(i, "")
+#define BHW_ROT_HI(i) BHW_ROT_I(i, "v_add_u32 %[b], %[c" #i "], %[b]\n\t")
+#define BHW_ROT_DISPATCH                                                                                               \
+                 "s_cmp_lt_i32 %[e], 1\n\ts_cbranch_scc1 0f\n\t"                                                       \
+                 "s_cmp_eq_u32 %[e], 1\n\ts_cbranch_scc1 1f\n\t"                                                       \
+                 "s_cmp_eq_u32 %[e], 2\n\ts_cbranch_scc1 2f\n\t"                                                       \
+                 "s_cmp_eq_u32 %[e], 3\n\ts_cbranch_scc1 3f\n\t"                                                       \
+                 "s_cmp_eq_u32 %[e], 4\n\ts_cbranch_scc1 4f\n\t"                                                       \
+                 "s_cmp_eq_u32 %[e], 5\n\ts_cbranch_scc1 5f\n\t"                                                       \
+                 "s_cmp_eq_u32 %[e], 6\n\ts_cbranch_scc1 6f\n\t"                                                       \
+                 "s_cmp_eq_u32 %[e], 7\n\ts_cbranch_scc1 7f\n\t"                                                       \
+                 "s_cmp_eq_u32 %[e], 8\n\ts_cbranch_scc1 8f\n\t"                                                       \
+                 "s_cmp_eq_u32 %[e], 9\n\ts_cbranch_scc1 9f\n\t"                                                       \
                  "s_branch 10f\n"
-                 BHW_ROT_I(0) BHW_ROT_I(1) BHW_ROT_I(2) BHW_ROT_I(3) BHW_ROT_I(4) BHW_ROT_I(5) BHW_ROT_I(6) BHW_ROT_I(7) BHW_ROT_I(8) BHW_ROT_I(9)
-                 "10:"
-                 : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [za] "+v"(zacc), [a] "=&v"(a), [b] "=&v"(b)
-                 : [e] "s"(e), [l0] "s"(lut[KA]), [l1] "s"(lut[KA + 1]), [l2] "s"(lut[KA + 2]), [l3] "s"(lut[KA + 3]), [l4] "s"(lut[KA + 4]),
-                   [l5] "s"(lut[KA + 5]), [l6] "s"(lut[KA + 6]), [l7] "s"(lut[KA + 7]), [l8] "s"(lut[KA + 8]), [l9] "s"(lut[KA + 9]),
-                   [k0] "n"(KA), [k1] "n"(KA + 1), [k2] "n"(KA + 2), [k3] "n"(KA + 3), [k4] "n"(KA + 4), [k5] "n"(KA + 5), [k6] "n"(KA + 6),
+#define BHW_ROT_OPERANDS                                                                                               \
+                 : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [za] "+v"(zacc), [a] "=&v"(a), [b] "=&v"(b)                  \
+                 : [e] "s"(e), [l0] "s"(lut[KA]), [l1] "s"(lut[KA + 1]), [l2] "s"(lut[KA + 2]), [l3] "s"(lut[KA + 3]), [l4] "s"(lut[KA + 4]), \
+                   [l5] "s"(lut[KA + 5]), [l6] "s"(lut[KA + 6]), [l7] "s"(lut[KA + 7]), [l8] "s"(lut[KA + 8]), [l9] "s"(lut[KA + 9]), \
+                   [k0] "n"(KA), [k1] "n"(KA + 1), [k2] "n"(KA + 2), [k3] "n"(KA + 3), [k4] "n"(KA + 4), [k5] "n"(KA + 5), [k6] "n"(KA + 6), \
                    [k7] "n"(KA + 7), [k8] "n"(KA + 8), [k9] "n"(KA + 9)
-                 : "vcc", "scc");
+    if constexpr (HI) {
+        constexpr int S = NITER - 1 - KA;                  // B >> (KA + i) = 2^(S - i)
+        static_assert(S >= 9 && S <= 30, "bias shifts");
+        asm volatile(BHW_ROT_DISPATCH
+                     BHW_ROT_HI(0) BHW_ROT_HI(1) BHW_ROT_HI(2) BHW_ROT_HI(3) BHW_ROT_HI(4) BHW_ROT_HI(5) BHW_ROT_HI(6) BHW_ROT_HI(7) BHW_ROT_HI(8) BHW_ROT_HI(9)
+                     "10:"
+                     BHW_ROT_OPERANDS,
+                       [c0] "n"(1 << S), [c1] "n"(1 << (S - 1)), [c2] "n"(1 << (S - 2)), [c3] "n"(1 << (S - 3)), [c4] "n"(1 << (S - 4)),
+                       [c5] "n"(1 << (S - 5)), [c6] "n"(1 << (S - 6)), [c7] "n"(1 << (S - 7)), [c8] "n"(1 << (S - 8)), [c9] "n"(1 << (S - 9))
+                     : "vcc", "scc");
+    } else {
+        asm volatile(BHW_ROT_DISPATCH
+                     BHW_ROT_PLAIN(0) BHW_ROT_PLAIN(1) BHW_ROT_PLAIN(2) BHW_ROT_PLAIN(3) BHW_ROT_PLAIN(4) BHW_ROT_PLAIN(5) BHW_ROT_PLAIN(6) BHW_ROT_PLAIN(7)
+                     BHW_ROT_PLAIN(8) BHW_ROT_PLAIN(9)
+                     "10:"
+                     BHW_ROT_OPERANDS
+                     : "vcc", "scc");
+    }
 #undef BHW_ROT_I
+#undef BHW_ROT_PLAIN
+#undef BHW_ROT_HI
+#undef BHW_ROT_DISPATCH
+#undef BHW_ROT_OPERANDS
+}
+
+// Timeline instrumentation (development builds only, -DBHW_BUILD_STAMPS; tools/build_timeline.py): every workgroup records the
+// 100 MHz wall clock at its phase boundaries -- 8 words per workgroup at g_build_stamps.
+#ifdef BHW_BUILD_STAMPS
+__device__ unsigned long long *g_build_stamps = nullptr;
+#define BHW_STAMP(i) do { if (g_build_stamps && (threadIdx.x & 63u) == 0u) atomicMax(&g_build_stamps[blockIdx.x * 8u + (i)], (unsigned long long)wall_clock64()); } while (0)
+#define BHW_STAMP_MIN(i) do { if (g_build_stamps && threadIdx.x == 0u) g_build_stamps[blockIdx.x * 8u + (i)] = (unsigned long long)wall_clock64(); } while (0)
+#else
+#define BHW_STAMP(i) do { } while (0)
+#define BHW_STAMP_MIN(i) do { } while (0)
+#endif
+
+// One packed table entry, stored at agent scope (sc1): written through the XCD's L2 to memory as it is produced.  With plain
+// (write-back) stores the whole table -- 17 MB, less than the eight L2s hold together -- stayed dirty in the L2s until the
+// end-of-kernel release wrote it back: 5 us during which nothing else ran (profiles/r04_ab_store_policy.txt: 0.1069 -> 0.1022 ms
+// per window; sc0 alone changes nothing; nontemporal stores make the build as fast but leave the table out of the memory-side
+// cache, and the combine pass then takes 94 us instead of 67).  The combine pass runs on other XCDs and reads the table through
+// their own L2s, so device scope is also what the data needs.
+template <typename T>
+__device__ __forceinline__ void table_store(void *__restrict__ table, uint32_t idx, T v)
+{
+    T *ptr = reinterpret_cast<T *>(table) + idx;
+    if constexpr (sizeof(T) == 1) asm volatile("global_store_byte %0, %1, off sc1" :: "v"(ptr), "v"((uint32_t)v) : "memory");
+    else asm volatile("global_store_short %0, %1, off sc1" :: "v"(ptr), "v"((uint32_t)v) : "memory");
 }
 
 template <int NITER, int FMT, int THREADS>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8))) void k_table_build_mirror(BhwBuildPlan plan, void *__restrict__ table)
 {
+    BHW_STAMP_MIN(0);
+#ifdef BHW_BUILD_STAMPS
+    if (g_build_stamps && threadIdx.x == 0u) {                       // where this workgroup runs: HW_ID (CU / SH / SE) and the XCD
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+        g_build_stamps[blockIdx.x * 8u + 6u] = hw;
+        g_build_stamps[blockIdx.x * 8u + 7u] = xcc;
+    }
+#endif
     static_assert(FMT == 2 || FMT == 3, "residual / nibble entries");
     static_assert(NITER >= 21 && NITER <= 32, "narrow state: 32-bit words");
-    static_assert(THREADS == 256 || THREADS == 512 || THREADS == 1024, "workgroup shapes");
+    static_assert(THREADS == 256 || THREADS == 1024, "workgroup shapes");
     constexpr uint32_t gpw = mirror_gpw(THREADS);               // own groups per workgroup
     constexpr uint32_t kHeads = mirror_heads_max(THREADS), kHeadsPad = mirror_heads_pad(THREADS);
     static_assert(gpw + 2 * kHeadsPad + 64 <= THREADS, "prefix lanes, two ranges of head chains, the tail-table wave");
@@ -360,10 +424,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8))) vo
     __shared__ int64_t gy[gpw];
     __shared__ int32_t gz[gpw];
     __shared__ int32_t gk[gpw];
-    __shared__ uint32_t gflag[gpw];                             // bit 0: leaf 0 met z == 0 inside the shared prefix; bit 1: narrow state
+    __shared__ uint32_t gflag[gpw];                             // bit 0: leaf 0 met z == 0 inside the shared prefix; bit 1: narrow state; bit 2: ... with x biased
     __shared__ uint32_t lut_s[32];
     __shared__ uint8_t tail_p[2 * kTailZ];                      // z_KS + kTailZ -> decision pattern of the tail
-    __shared__ __attribute__((aligned(16))) int8_t tail_d[64 * 64];
+    __shared__ __attribute__((aligned(16))) int8_t tail_d[kTailRows * 64 + 16];   // 65 rows of 64 patterns (+ padding to whole 16-byte packets)
     constexpr uint32_t kWorkMax = 8 * gpw;           // images to run as chains of their own (expected ~0.6 per group)
     __shared__ uint32_t work_n;
     __shared__ uint32_t work_u[kWorkMax];
@@ -389,7 +453,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8))) vo
     if (threadIdx.x >= (uint32_t)THREADS - 64u) {
         const uint32_t t3 = threadIdx.x - ((uint32_t)THREADS - 64u);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) reinterpret_cast<int4 *>(tail_d)[t3 + 64u * q] = reinterpret_cast<const int4 *>(kTailD.v)[t3 + 64u * q];
+        for (int q = 0; q < 5; ++q)
+            if (t3 + 64u * q < (uint32_t)(kTailRows * 64 + 16) / 16u) reinterpret_cast<int4 *>(tail_d)[t3 + 64u * q] = reinterpret_cast<const int4 *>(kTailD.v)[t3 + 64u * q];
 #pragma unroll
         for (int q = 0; q < 2 * kTailZ / 64; ++q) {
             const uint32_t zi = t3 + 64u * (uint32_t)q;
@@ -465,12 +530,18 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8))) vo
         // narrow state: every later x_k, y_k of every leaf stays inside [0, 2^NITER) (see the head comment)
         const int64_t drift = ((int64_t)1 << (NITER - k + 1)) + 2, lim = (int64_t)1 << NITER;
         const bool narrow = x >= drift && y >= drift && x + drift < lim && y + drift < lim;
-        gx[threadIdx.x] = x;
+        // biased narrow state (rot_narrow_block<.., true>): x - B fits the word and x stays below row 65 of the tail table; only groups
+        // that enter the ten-rotation block (tools/sim_build.cpp checks every entry of such tables against the plain chain)
+        constexpr int64_t kBias = (int64_t)1 << (NITER - 1);
+        const bool hi = !narrow && k >= KS - 10 && y >= drift && y + drift < lim && x - kBias >= drift && x - kBias + drift < ((int64_t)1 << 32) &&
+                        x + drift < lim + ((int64_t)1 << KS);
+        gx[threadIdx.x] = hi ? x - kBias : x;
         gy[threadIdx.x] = y;
         gz[threadIdx.x] = zf;
         gk[threadIdx.x] = k;
-        gflag[threadIdx.x] = zero0 | (narrow ? 2u : 0u);
+        gflag[threadIdx.x] = zero0 | (narrow || hi ? 2u : 0u) | (hi ? 4u : 0u);
     }
+    BHW_STAMP(1);                                                    // last wave to reach the first barrier
     __syncthreads();
 
     // the records themselves, once per workgroup: the groups read them back with one ds_read_b128 each
@@ -491,6 +562,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8))) vo
         }
     }
     __syncthreads();
+    BHW_STAMP_MIN(2);
     auto record_of = [&](int w, uint32_t cell) -> int4 { return hrec[w][cell - cell_lo[w]]; };   // cell in [cell_lo[w], cell_lo[w] + n_cell[w])
     auto record = [&](int w, uint32_t cell) -> int4 {              // the same for a wave-uniform cell (a broadcast read)
         return record_of(w, __builtin_amdgcn_readfirstlane(cell));
@@ -502,10 +574,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8))) vo
         const int32_t dc = c - p.x, ds = sn - p.y;
         if constexpr (FMT == 3) {
             if (plan.check_flag && !(fits_bits(dc, 4) && fits_bits(ds, 4))) atomicOr(plan.check_flag, 1u);
-            reinterpret_cast<uint8_t *>(table)[idx] = (uint8_t)(((uint32_t)dc & 0xFu) | (((uint32_t)ds & 0xFu) << 4));
+            table_store<uint8_t>(table, idx, (uint8_t)(((uint32_t)dc & 0xFu) | (((uint32_t)ds & 0xFu) << 4)));
         } else {
             if (plan.check_flag && !(fits_bits(dc, 8) && fits_bits(ds, 8))) atomicOr(plan.check_flag, 1u);
-            reinterpret_cast<uint16_t *>(table)[idx] = (uint16_t)(((uint32_t)dc & 0xFFu) | (((uint32_t)ds & 0xFFu) << 8));
+            table_store<uint16_t>(table, idx, (uint16_t)(((uint32_t)dc & 0xFFu) | (((uint32_t)ds & 0xFFu) << 8)));
         }
     };
 
@@ -521,6 +593,19 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8))) vo
     for (uint32_t gi = wave; gi < gpw; gi += THREADS / 64) {
         const uint32_t g = __builtin_amdgcn_readfirstlane(group0 + gi);   // (kept in a vector register otherwise, and the cell arithmetic with it)
         if (g >= n_groups) break;
+        // Issue priority by progress.  The SIMD's arbiter serves the oldest wave first, so of the two workgroups of a CU the one
+        // that was started first runs ahead, finishes its 16 rounds of groups ~12 us before the other (profiles/r04_build_timeline.txt:
+        // 21 against 33 us) and leaves the CU half empty for the rest of the pass -- and there is no second round of workgroups to
+        // refill it.  A wave lowers its own priority every four groups: whoever is behind is served first, the waves of both
+        // workgroups stay within four groups of each other and the CU stays full until the end (0.1076 -> 0.1047 ms per window,
+        // profiles/r04_ab_prio.txt).
+        {
+            const uint32_t it = (gi - wave) / (uint32_t)(THREADS / 64);
+            if (it == 0u) __builtin_amdgcn_s_setprio(3);
+            else if (it == 4u) __builtin_amdgcn_s_setprio(2);
+            else if (it == 8u) __builtin_amdgcn_s_setprio(1);
+            else if (it == 12u) __builtin_amdgcn_s_setprio(0);
+        }
         const int k0 = __builtin_amdgcn_readfirstlane(gk[gi]);
         const uint32_t gf = __builtin_amdgcn_readfirstlane(gflag[gi]);
         int32_t z = (int32_t)((uint32_t)gz[gi] + (lane << s));
@@ -542,21 +627,37 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8))) vo
                 BHW_NARROW(9) BHW_NARROW(10) BHW_NARROW(11) BHW_NARROW(12) BHW_NARROW(13) BHW_NARROW(14) BHW_NARROW(15)
 #undef BHW_NARROW
             }
-            rot_narrow_block<KA>(x, y, z, zacc, plan.lut, k0 - KA);
+            const bool hi = (gf & 4u) != 0u;                          // scalar: x holds x - 2^(NITER-1)
+            if (hi) rot_narrow_block<KA, NITER, true>(x, y, z, zacc, plan.lut, k0 - KA);
+            else rot_narrow_block<KA, NITER, false>(x, y, z, zacc, plan.lut, k0 - KA);
             zmask = __builtin_amdgcn_ballot_w64(zacc == 0u);
+            const uint32_t xrow6 = hi ? (1u << (NITER - 1 - KS + 6)) : 0u;   // (B >> KS) << 6: the bias in the tail table's row index
+            const uint32_t bias_out = hi ? ((1u << (NITER - 1)) >> plan.out_shr) : 0u;   // B >> out_shr
             static_assert(KS <= 26, "unrolled to rotation 25");
             constexpr uint32_t lowm = (1u << KS) - 1u;
             const uint32_t zi = (uint32_t)(z + kTailZ);              // own pattern at zi, the image's (z -> -z) at 2 kTailZ - zi
             const uint32_t mx = (x + 128u) & lowm, my = (y + 128u) & lowm;      // margin of 128 to both ends of the low KS bits
             const uint32_t unsafe = (uint32_t)((mx < my ? mx : my) < 256u) | (uint32_t)((zi - 1u) >= (uint32_t)(2 * kTailZ - 1));
             if (__builtin_amdgcn_ballot_w64(unsafe != 0u) == 0ull) {
-                const uint32_t xx = (x >> KS) << 6, yy = (y >> KS) << 6;   // row of D: x, y < 2^NITER, so x >> KS < 64
+                const uint32_t xx = ((x >> KS) << 6) + xrow6, yy = (y >> KS) << 6;   // row of D: y < 2^NITER, so y >> KS < 64; x >> KS <= 64
                 const uint32_t p1 = tail_p[zi], p2 = tail_p[2u * kTailZ - zi];
                 const int32_t dx1 = tail_d[p1 + yy], dy1 = tail_d[p1 + xx], dx2 = tail_d[p2 + xx], dy2 = tail_d[p2 + yy];
-                c1 = (int32_t)((x - (uint32_t)dx1) >> plan.out_shr);
+                c1 = (int32_t)(((x - (uint32_t)dx1) >> plan.out_shr) + bias_out);
                 s1 = (int32_t)((y + (uint32_t)dy1) >> plan.out_shr);
                 c2 = (int32_t)((y - (uint32_t)dx2) >> plan.out_shr);
-                s2 = (int32_t)((x + (uint32_t)dy2) >> plan.out_shr);
+                s2 = (int32_t)(((x + (uint32_t)dy2) >> plan.out_shr) + bias_out);
+            } else if (hi) {
+                // (rare: a lane outside the tail table's margins in a biased group) the six rotations on the 64-bit state
+                int64_t xw = (int64_t)x + ((int64_t)1 << (NITER - 1)), yw = (int64_t)y;
+                int64_t x2 = yw, y2 = xw;
+                int32_t z2 = -z;
+#pragma unroll 1
+                for (int k = KS; k < NITER; ++k) {
+                    rot_step_dyn(xw, yw, z, k, lut_s[k], true);
+                    rot_step_dyn(x2, y2, z2, k, lut_s[k], true);
+                }
+                c1 = (int32_t)(xw >> plan.out_shr); s1 = (int32_t)(yw >> plan.out_shr);
+                c2 = (int32_t)(x2 >> plan.out_shr); s2 = (int32_t)(y2 >> plan.out_shr);
             } else {
                 uint32_t x2 = y, y2 = x;
                 int32_t z2 = -z;
@@ -623,6 +724,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8))) vo
             store_entry(idx_i - idx, c2, s2, rec2, um & fmask);
         }
     }
+    BHW_STAMP_MIN(3);                                                // first wave done with its groups
+    BHW_STAMP(4);                                                    // last wave done
     // ---- the deferred images: one lane each.  The chain is unrolled on the scalar ROM words (the rolled loop on the LDS copy kept
     // every workgroup 1.5 us longer at the end of the kernel, where nothing else is left to overlap it) ----
     __syncthreads();
@@ -635,6 +738,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8))) vo
         for (int r = 1; r < n_iter; ++r) rot_step(xf, yf, zf, r, plan.lut[r]);     // (restarting from the group's parked state, per-lane start rotation: +0.3 us)
         store_entry(tab_index(um, plan.log2_entries, plan.tab_split), (int32_t)(xf >> plan.out_shr), (int32_t)(yf >> plan.out_shr), record_of(1, um >> d), um & fmask);
     }
+    BHW_STAMP(5);
 }
 
 // Table strategy, pass 1, small tables: one lane per entry, the whole chain unrolled in the mad form, plain natural layout.
@@ -694,6 +798,14 @@ int bhwk_sincos_sweep(const BhwLaunch &l, const BhwCordicCfg &c, uint64_t theta0
     return finish(hipSuccess);
 }
 
+#ifdef BHW_BUILD_STAMPS
+extern "C" int bhw_dbg_build_stamps(void *d_words)      // 8 x uint64 per workgroup of the mirror kernel, zeroed by the caller; NULL = off
+{
+    unsigned long long *p = (unsigned long long *)d_words;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_build_stamps), &p, sizeof p);
+}
+#endif
+
 int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c_in, int32_t *d_table)
 {
     const BhwCordicCfg c = table_layout(c_in);
@@ -745,12 +857,8 @@ int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c_in, int32_t *d_ta
             const dim3 mgrid((own_groups + mgpw - 1) / mgpw), mblock(threads);
             plan.groups_per_wg = mgpw;
             switch (c.n_iter) {
-#if defined(BHW_MIRROR_THREADS) && BHW_MIRROR_THREADS == 512      /* A/B builds only (tools/ab_inproc.py) */
-#define BHW_CASE_MT(N, F) BHW_LAUNCH((k_table_build_mirror<N, F, 512>), mgrid, mblock, 0, st, plan, (void *)d_table)
-#else
 #define BHW_CASE_MT(N, F) do { if (threads == 1024u) BHW_LAUNCH((k_table_build_mirror<N, F, 1024>), mgrid, mblock, 0, st, plan, (void *)d_table); \
                                else                  BHW_LAUNCH((k_table_build_mirror<N, F, 256>), mgrid, mblock, 0, st, plan, (void *)d_table); } while (0)
-#endif
 #define BHW_CASE_M(N) case N: if (fmt == 2) BHW_CASE_MT(N, 2); else BHW_CASE_MT(N, 3); break;
                 BHW_CASE_M(21) BHW_CASE_M(22) BHW_CASE_M(23) BHW_CASE_M(24) BHW_CASE_M(25) BHW_CASE_M(26) BHW_CASE_M(27) BHW_CASE_M(28)
                 BHW_CASE_M(29) BHW_CASE_M(30) BHW_CASE_M(31) BHW_CASE_M(32)

@@ -441,6 +441,7 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
                         int32_t v;
                         if constexpr (MODE != 2 && decltype(full_width)::value) v = acc_value(acc[b][h][j]);   // W == 32: nothing to wrap
                         else v = final_value(b, h, j);
+                        // (plain write-back stores: at agent or system scope -- sc1, sc0 sc1 -- the pass takes 91 us instead of 67, profiles/r04_ab_store_scope.txt)
                         *reinterpret_cast<int32_t *>(reinterpret_cast<char *>(img) + (rr[b] << 2)) = v;
                     }
                 }

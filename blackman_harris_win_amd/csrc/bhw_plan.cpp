@@ -286,12 +286,7 @@ bool bhwk_build_mirror_applies(const BhwCordicCfg &c, uint32_t entries)
 // a 256-CU device its two workgroups (tables of 2^24 entries and more), 256 threads below (profiles/r04_ab_build_wg.txt)
 unsigned bhwk_build_mirror_threads(uint32_t entries)
 {
-#ifdef BHW_MIRROR_THREADS
-    (void)entries;
-    return BHW_MIRROR_THREADS;
-#else
     return entries >= (1u << 24) ? 1024u : 256u;
-#endif
 }
 
 BhwTableLayout bhwp_table_layout(uint64_t E, uint32_t tab_dlog)

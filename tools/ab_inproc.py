@@ -109,6 +109,34 @@ def main():
                 times[i].append(e0.elapsed_time(e1) / inner)
     for f, t in zip(variants, times):
         print("%-44s median %.4f ms  min %.4f  max %.4f" % ("[" + f + "]", statistics.median(t), min(t), max(t)))
+    if os.environ.get("AB_SPLIT"):
+        # the two passes of the table strategy on their own: an event between build and combine (bhw_exec.event_after_build),
+        # one call at a time (the events of back-to-back calls would serialise the host), median over AB_SPLIT_N calls
+        n_split = int(os.environ.get("AB_SPLIT_N", "300"))
+        for f, L in zip(variants, libs):
+            L.bhw_generate_device_ex.argtypes = [ctypes.POINTER(binding.BhwParams), ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64,
+                                                 ctypes.c_void_p, ctypes.POINTER(binding.BhwExec)]
+            evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n_split)]
+            for trio in evs:
+                for e in trio:
+                    e.record()
+            torch.cuda.synchronize()
+            ex = binding.BhwExec()
+            ex.struct_size = ctypes.sizeof(binding.BhwExec)
+            for _ in range(100):
+                call(L)
+            for e0, em, e1 in evs:
+                ex.event_after_build = em.cuda_event
+                e0.record()
+                rc = L.bhw_generate_device_ex(ctypes.byref(p), 0, ctypes.c_void_p(st), 0, n, ctypes.c_void_p(out.data_ptr()), ctypes.byref(ex))
+                assert rc == 0, rc
+                e1.record()
+            torch.cuda.synchronize()
+            b = [t[0].elapsed_time(t[1]) * 1e3 for t in evs]
+            c = [t[1].elapsed_time(t[2]) * 1e3 for t in evs]
+            print("%-44s build %.1f us (p10 %.1f p90 %.1f)  combine %.1f us (p10 %.1f p90 %.1f)" % (
+                "[" + f + "]", statistics.median(b), sorted(b)[n_split // 10], sorted(b)[9 * n_split // 10],
+                statistics.median(c), sorted(c)[n_split // 10], sorted(c)[9 * n_split // 10]))
 
 
 if __name__ == "__main__":

@@ -5,7 +5,10 @@
 //       the rotations run on 32-bit unsigned words with logical shifts;
 //   (3) table tail: for the last TAIL rotations  (y_k >> k) == (y_KS >> KS) >> (k - KS)  as long as the low KS bits of x_KS, y_KS
 //       keep a margin of 128 to both ends, so  x_end = x_KS - D[p][y_KS >> KS],  y_end = y_KS + D[p][x_KS >> KS]  with
-//       D[p][v] = sum_j sigma_j(p) (v >> j)  and p the decision pattern looked up from z_KS.
+//       D[p][v] = sum_j sigma_j(p) (v >> j)  and p the decision pattern looked up from z_KS;
+//   (4) biased narrow state (round 4): a group whose x runs up to 2^NITER (1 + eps) -- the first third of a degree of the octant,
+//       where x alone does not fit the 32-bit word -- keeps x - 2^(NITER-1) in the word instead:  (x >> k) = ((x - B) >> k) + (B >> k)
+//       exactly, B = 2^(NITER-1) being a multiple of 2^k for every k < NITER, and the tail table gets a 65th row (x >> KS = 64).
 // Every entry of the first-quadrant table is compared with the plain chain (the rotation loop of
 // hls/windows/win_function.cpp:110-125 | cpp/cordic_sincos.cpp:49-63 | src/cordic_dds.vhd:197-213).
 // Test infrastructure / design evidence only: nothing here is linked into the product.
@@ -86,15 +89,18 @@ int main(int argc, char **argv)
         }
         Pz[zi] = (uint16_t)p;
     }
-    int8_t D[64][64];
+    int8_t D[64][65];
     for (unsigned p = 0; p < 64; ++p)
-        for (int v = 0; v < 64; ++v) {
+        for (int v = 0; v < 65; ++v) {
             int d = 0;
             for (int j = 0; j < TAIL; ++j) d += ((p >> j) & 1u) ? -(v >> j) : (v >> j);    // sigma = +1 when z >= 0
             D[p][v] = (int8_t)d;
         }
 
     std::vector<int32_t> gc(E, INT32_MIN), gs(E, INT32_MIN);
+    uint64_t hi_groups = 0;
+    const int KA = KS - 10;                                                  // the kernel's ten-rotation block starts here
+    const int64_t BX = (int64_t)1 << (N - 1);                                // bias of the biased narrow state
     uint64_t n_groups = E >> 7, wide_groups = 0, unsafe_waves = 0, unsafe_lanes = 0, zero_lanes = 0, zero_prefix = 0;
     const int64_t LIM = (int64_t)1 << N;
     auto full_chain = [&](uint32_t u, int32_t &oc, int32_t &os) {           // the kernel's deferred / fallback chain
@@ -118,8 +124,16 @@ int main(int argc, char **argv)
         zero_prefix += zero0;
         // narrow-state test (scalar, per group)
         const int64_t Dr = ((int64_t)1 << (N - k0 + 1)) + 2;
-        const bool narrow = X >= Dr && Y >= Dr && X + Dr < LIM && Y + Dr < LIM && N <= 32;
+        bool narrow = X >= Dr && Y >= Dr && X + Dr < LIM && Y + Dr < LIM && N <= 32;
+        // biased: x - B in [Dr, 2^32 - Dr), x below 65 * 2^KS (row 64 of the tail table), y as in the plain narrow state; only groups
+        // that enter the ten-rotation block (split rotation >= KA)
+        const bool hi = !narrow && N <= 32 && k0 >= KA && Y >= Dr && Y + Dr < LIM && X - BX >= Dr && X - BX + Dr < ((int64_t)1 << 32) &&
+                        X + Dr < LIM + ((int64_t)1 << KS);
+        const int64_t bias = hi ? BX : 0;
+        hi_groups += hi;
+        narrow = narrow || hi;
         wide_groups += !narrow;
+        if (!narrow && getenv("SIM_VERBOSE")) fprintf(stderr, "wide g=%llu k0=%d X=%lld Y=%lld Dr=%lld\n", (unsigned long long)g, k0, (long long)X, (long long)Y, (long long)Dr);
         bool wave_unsafe = false;
         struct Lane { int64_t x, y, z; bool zero; } L[64];
         for (int lane = 0; lane < 64; ++lane) {
@@ -128,19 +142,19 @@ int main(int argc, char **argv)
             for (int k = k0; k < KS; ++k) {
                 zero |= z == 0;
                 if (narrow) {
-                    if (x < 0 || y < 0 || x >= LIM || y >= LIM) { fprintf(stderr, "narrow range violated g=%llu lane=%d k=%d\n", (unsigned long long)g, lane, k); return 1; }
-                    const uint32_t xu = (uint32_t)x, yu = (uint32_t)y;
-                    const uint32_t a = yu >> k, b = xu >> k;                  // logical shifts on 32-bit words
+                    if (x - bias < 0 || y < 0 || x - bias >= ((int64_t)1 << 32) || y >= LIM) { fprintf(stderr, "narrow range violated g=%llu lane=%d k=%d\n", (unsigned long long)g, lane, k); return 1; }
+                    const uint32_t xu = (uint32_t)(x - bias), yu = (uint32_t)y;
+                    const uint32_t a = yu >> k, b = (xu >> k) + (uint32_t)(bias >> k);     // logical shifts on 32-bit words
                     uint32_t xn, yn;
                     if (z < 0) { xn = xu + a; yn = yu - b; z += c.lut[k]; } else { xn = xu - a; yn = yu + b; z -= c.lut[k]; }
-                    x = xn; y = yn;
+                    x = (int64_t)xn + bias; y = yn;
                 } else step(x, y, z, k, c.lut[k]);
             }
             L[lane] = Lane{x, y, z, zero};
             if (narrow) {
-                if (x < 0 || y < 0 || x >= LIM || y >= LIM) { fprintf(stderr, "narrow range violated at KS\n"); return 1; }
+                if (x - bias < 0 || y < 0 || x - bias >= ((int64_t)1 << 32) || y >= LIM) { fprintf(stderr, "narrow range violated at KS\n"); return 1; }
                 const uint32_t lowm = (1u << KS) - 1u;
-                const bool ok = (((uint32_t)x + 128u) & lowm) >= 256u && (((uint32_t)y + 128u) & lowm) >= 256u &&
+                const bool ok = (((uint32_t)(x - bias) + 128u) & lowm) >= 256u && (((uint32_t)y + 128u) & lowm) >= 256u &&
                                 (uint64_t)(z + ZB) < (uint64_t)(2 * ZB);
                 if (!ok) { wave_unsafe = true; ++unsafe_lanes; }
             }
@@ -152,13 +166,15 @@ int main(int argc, char **argv)
             int64_t x2 = y, y2 = x, z2 = -z;
             int32_t oc, os, oc2, os2;
             if (narrow && !wave_unsafe) {
-                const uint32_t xx = (uint32_t)x >> KS, yy = (uint32_t)y >> KS;
-                if (xx > 63 || yy > 63) { fprintf(stderr, "tail operand out of range\n"); return 1; }
+                const uint32_t xu = (uint32_t)(x - bias);
+                const uint32_t xx = (xu >> KS) + (uint32_t)(bias >> KS), yy = (uint32_t)y >> KS;
+                if (xx > 64 || yy > 63) { fprintf(stderr, "tail operand out of range\n"); return 1; }
                 const unsigned p = Pz[z + ZB], p2 = Pz[-z + ZB];
-                oc = (int32_t)(((uint32_t)x - (uint32_t)(int32_t)D[p][yy]) >> c.out_shr);
+                const uint32_t bo = (uint32_t)(bias >> c.out_shr);
+                oc = (int32_t)(((xu - (uint32_t)(int32_t)D[p][yy]) >> c.out_shr) + bo);
                 os = (int32_t)(((uint32_t)y + (uint32_t)(int32_t)D[p][xx]) >> c.out_shr);
                 oc2 = (int32_t)(((uint32_t)y - (uint32_t)(int32_t)D[p2][xx]) >> c.out_shr);
-                os2 = (int32_t)(((uint32_t)x + (uint32_t)(int32_t)D[p2][yy]) >> c.out_shr);
+                os2 = (int32_t)(((xu + (uint32_t)(int32_t)D[p2][yy]) >> c.out_shr) + bo);
             } else {
                 for (int k = KS; k < N; ++k) { step(x, y, z, k, c.lut[k]); step(x2, y2, z2, k, c.lut[k]); }
                 oc = (int32_t)(x >> c.out_shr); os = (int32_t)(y >> c.out_shr);
@@ -176,8 +192,8 @@ int main(int argc, char **argv)
     for (uint32_t u = 0; u < E; ++u)
         if (gc[u] != rc[u] || gs[u] != rs[u]) { if (bad < 5) fprintf(stderr, "mismatch u=%u got (%d,%d) want (%d,%d)\n", u, gc[u], gs[u], rc[u], rs[u]); ++bad; }
     printf("model %d PW %d W %d P %d: entries %u, groups %llu, wide-state groups %llu (%.2f %%), waves with an unsafe tail lane %llu (lanes %llu), "
-           "deferred images %llu (prefix zeros %llu), mismatches %llu\n", model, PW, W, P, E, (unsigned long long)n_groups,
+           "deferred images %llu (prefix zeros %llu), biased-narrow groups %llu, mismatches %llu\n", model, PW, W, P, E, (unsigned long long)n_groups,
            (unsigned long long)wide_groups, 100.0 * wide_groups / n_groups, (unsigned long long)unsafe_waves, (unsigned long long)unsafe_lanes,
-           (unsigned long long)zero_lanes, (unsigned long long)zero_prefix, (unsigned long long)bad);
+           (unsigned long long)zero_lanes, (unsigned long long)zero_prefix, (unsigned long long)hi_groups, (unsigned long long)bad);
     return bad ? 1 : 0;
 }
