@@ -189,14 +189,59 @@ __device__ __forceinline__ uint32_t ld_nibble(const void *__restrict__ table, ui
 // MASKED: the launch produces only some of the eight images (a contiguous index range of the window that is a whole number of
 // eighths -- one device's contiguous shard of a window split over 2, 4 or 8): a gather is skipped when no wanted image reads it
 // (odd harmonics: the h = 0 / h = 1 gathers), sums of an unwanted half are not formed, unwanted images are not stored.
+// Timeline instrumentation (development builds only, -DBHW_COMBINE_STAMPS; tools/combine_timeline.py): 8 words per workgroup.
+#ifdef BHW_COMBINE_STAMPS
+__device__ unsigned long long *g_combine_stamps = nullptr;
+// one lane per wave, by narrowing EXEC inside one asm statement: a C++ `if (lane == 0)` around an atomic makes the compiler treat
+// scalars computed after it as divergent, and the kernel's scalar-operand asm statements no longer compile
+__device__ __forceinline__ void cstamp(unsigned long long *slot, bool is_max)
+{
+    const unsigned long long now = wall_clock64();
+    unsigned long long sv;
+    if (is_max) asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_umax_x2 %1, %2, off\n\ts_mov_b64 exec, %0" : "=&s"(sv) : "v"(slot), "v"(now) : "memory");
+    else        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_umin_x2 %1, %2, off\n\ts_mov_b64 exec, %0" : "=&s"(sv) : "v"(slot), "v"(now) : "memory");
+}
+#define BHW_CSTAMP_MAX(i) do { if (g_combine_stamps) cstamp(g_combine_stamps + blockIdx.x * 8u + (i), true); } while (0)
+#define BHW_CSTAMP_MIN(i) do { if (g_combine_stamps) cstamp(g_combine_stamps + blockIdx.x * 8u + (i), false); } while (0)
+extern "C" int bhw_dbg_combine_stamps(void *d_words)      // 8 x uint64 per workgroup; words 0, 2 preset to ~0 (minima), the others to 0; NULL = off
+{
+    unsigned long long *p = (unsigned long long *)d_words;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_combine_stamps), &p, sizeof p);
+}
+#else
+#define BHW_CSTAMP_MAX(i) do { } while (0)
+#define BHW_CSTAMP_MIN(i) do { } while (0)
+#endif
+
+// Workgroup of the 15-run tiles: ONE part (192 lanes, three waves), five workgroups per tile.  The tile's five thread groups
+// share nothing but table lines -- every wave stages its own records, there is no barrier -- and a workgroup gives its wave
+// slots back only when its last wave is done: as one 960-thread workgroup (rounds 1 - 3) the waves that were served first (the
+// arbiter prefers the oldest) reached their stores 3 us before the last ones of an ~10 us life (profiles/r04_combine_timeline.txt),
+// and the last of the 5.7 rounds of 512 such workgroups ran a third empty.  0.1002 -> 0.0967 ms per window, combine pass 67.7 ->
+// 63.5 us (profiles/r04_ab_tile_wg.txt; one wave per workgroup ties: 0.0972).  The five workgroups of a tile are dealt to the same
+// XCD one after the other, so the sibling runs still meet in one L2.
+// (The one- and three-run tiles of windows of up to five terms keep 960-thread workgroups: 192 there measured a tie, 0.0821 / 0.0816 ms
+// for BH-4 2^26 at 24 bits.)
+constexpr int kTileWg = kTileLanes;
+constexpr int tile_wg_of(int nb) { return nb >= 15 ? kTileWg : kTileThreads; }
 template <int NB, int MODE, int FMT, bool FAST = false, bool MASKED = false>
-__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 4 : 8))) void k_table_combine_tile(BhwCordicCfg cfg, BhwWinCfg win, BhwTilePlan tp,
+__global__ __launch_bounds__(tile_wg_of(NB)) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? 4 : 8))) void k_table_combine_tile(BhwCordicCfg cfg, BhwWinCfg win, BhwTilePlan tp,
                                                                       const void *__restrict__ table, int32_t *__restrict__ out)
 {
     // VHDL rule: the W+2-bit sum as two words (Sum32) in general; FAST instances are launched only when the sum of the |a_k| stays
     // below 2^31 (every term b_k is at most |a_k| + 1 in magnitude), so the exact sum is one 32-bit word
     constexpr bool kWideSum = MODE == 2 && !FAST;
     using acc_t = typename std::conditional<kWideSum, Sum32, int32_t>::type;
+    BHW_CSTAMP_MIN(0);                                               // first wave of the workgroup starts
+    BHW_CSTAMP_MAX(1);                                               // last wave starts
+#ifdef BHW_COMBINE_STAMPS
+    if (g_combine_stamps) {                                          // (every lane stores the same two words: no divergence)
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+        g_combine_stamps[blockIdx.x * 8u + 6u] = hw;
+        g_combine_stamps[blockIdx.x * 8u + 7u] = xcc;
+    }
+#endif
     const uint32_t lq = cfg.phi_width - 2;
     const uint32_t E = 1u << lq, emask = E - 1u, H = E >> 1, hmask = H - 1u;
     const uint32_t W = cfg.dat_width;
@@ -212,13 +257,21 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
     // Workgroups are dealt round-robin over the 8 XCDs (block b and b + 8 share an L2).  The tiles are renumbered so
     // that each XCD sweeps a contiguous eighth of the ring (neighbouring tiles share table lines at their run boundaries and the
     // 16-byte records of the residual format).
-    uint32_t tile_of_block = blockIdx.x;
+    constexpr int kWgThreads = tile_wg_of(NB);
+    constexpr uint32_t kWgPerTile = kTileThreads / kWgThreads;      // workgroups per tile
+    constexpr uint32_t kWgPerPart = kLanes / kWgThreads;            // ... per part: 1 for the 192-lane parts of a 15-run tile, 5 for the 960-lane runs of the others
+    static_assert(kWgPerPart * kWgThreads == kLanes && kWgPerPart * kParts == kWgPerTile, "a workgroup lies inside one part");
+    uint32_t tile_of_block = blockIdx.x / kWgPerTile, part_of_block = blockIdx.x % kWgPerTile;
     {
-        const uint32_t per = gridDim.x >> 3, main = per << 3;       // tiles per XCD in the evenly divisible part
-        if (blockIdx.x < main) tile_of_block = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+        const uint32_t per = (gridDim.x / kWgPerTile) >> 3, main = (per << 3) * kWgPerTile;   // tiles per XCD in the evenly divisible part
+        if (blockIdx.x < main) {
+            const uint32_t j = blockIdx.x >> 3;                     // position in this XCD's sequence of workgroups
+            tile_of_block = (blockIdx.x & 7u) * per + j / kWgPerTile;
+            part_of_block = j % kWgPerTile;
+        }
     }
-    const uint32_t part = __builtin_amdgcn_readfirstlane(threadIdx.x / kLanes);   // wave-uniform: kLanes is a multiple of 64
-    const uint32_t lane_in_part = threadIdx.x % kLanes;
+    const uint32_t part = kWgPerTile > 1 ? part_of_block / kWgPerPart : __builtin_amdgcn_readfirstlane(threadIdx.x / kLanes);   // wave-uniform: kLanes is a multiple of 64
+    const uint32_t lane_in_part = kWgPerTile > 1 ? (part_of_block % kWgPerPart) * kWgThreads + threadIdx.x : threadIdx.x % kLanes;
     constexpr bool kLdsRec = (FMT == 2 || FMT == 3) && NB >= 15 && kLanes == kTileLanes;
     uint32_t rec_meta = 0;                                           // slot -> (K, g, j) of the record staging below, fetched first
     if constexpr (kLdsRec) rec_meta = kRecMeta.v[threadIdx.x & 63u];
@@ -230,7 +283,7 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
         rr[b] = (start + (lane_in_part + kLanes - (start & 63u)) % kLanes) & hmask;
     }
     // records of the cells this wave's runs touch, staged in shared memory (see above)
-    constexpr int kWavesWg = kTileThreads / 64;
+    constexpr int kWavesWg = kWgThreads / 64;
     __shared__ int4 rec_s[kLdsRec ? kWavesWg * NR * kRecPerRun : 1];
     uint32_t rbias[kRecSets][NR];                                    // scalar: byte offset of "cell 0" of set si, run b in rec_s
     uint32_t qpack[NR];                                              // scalar: quadrant of set si, run b in bits 2 si, 2 si + 1
@@ -513,8 +566,12 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(MO
         init_acc(std::integral_constant<int, 1>{}); run_harmonics(std::integral_constant<int, 1>{}); store_runs(std::integral_constant<int, 1>{});
         init_acc(std::integral_constant<int, 2>{}); run_harmonics(std::integral_constant<int, 2>{}); store_runs(std::integral_constant<int, 2>{});
     } else {
-        init_acc(std::integral_constant<int, -1>{}); run_harmonics(std::integral_constant<int, -1>{}); store_runs(std::integral_constant<int, -1>{});
+        init_acc(std::integral_constant<int, -1>{}); run_harmonics(std::integral_constant<int, -1>{});
+        BHW_CSTAMP_MIN(2);                                           // first wave reaches its stores
+        BHW_CSTAMP_MAX(3);                                           // last wave reaches its stores
+        store_runs(std::integral_constant<int, -1>{});
     }
+    BHW_CSTAMP_MAX(4);                                               // last wave has issued its stores
 }
 
 // ---------------------------------------------------------------------------------------
@@ -709,7 +766,8 @@ int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c_in, 
     const bool masked = tp.img_mask != 0xFFu;                       // some of the eight images only (bhwk_tile_images_applicable)
     if (masked && (nb != 15 || w.apply_x != nullptr || tp.img_mask == 0u)) return (int)hipErrorInvalidValue;
     const int mode = (w.combine != BHW_COMBINE_HLS) ? 2 : (c.ones_neg ? 1 : 0);
-    const dim3 grid(tile_count), block(kTileThreads);
+    const uint32_t wg_threads = (uint32_t)tile_wg_of(nb);
+    const dim3 grid(tile_count * ((uint32_t)kTileThreads / wg_threads)), block(wg_threads);
     const bool fast = bhwp_tile_fast(c, w, nb);                     // one-instruction products (and, VHDL rule, one-word sums)
 #define BHW_LAUNCH_TILE_MFK(NB, M, F, K)                                                                                 \
     do {                                                                                                                 \
