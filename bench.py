@@ -97,7 +97,8 @@ def cpu_baseline(target_seconds=12.0, max_threads=16):
 def sources_sha16():
     """sha256 prefix of the kernel + ABI sources: ties a committed PMC summary to the code it was measured on."""
     h = hashlib.sha256()
-    for f in ("bhw_device.h", "bhw_build.hip", "bhw_combine.hip", "bhw_direct.hip", "bhw_fused.hip", "bhw_api.cpp", "bhw_internal.h"):
+    for f in ("bhw_device.h", "bhw_build.hip", "bhw_combine.hip", "bhw_direct.hip", "bhw_fused.hip", "bhw_taylor.hip", "bhw_api.cpp", "bhw_plan.cpp",
+              "bhw_plan.h", "bhw_internal.h"):
         with open(os.path.join(ROOT, "blackman_harris_win_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -122,6 +123,24 @@ def pmc_traffic():
         src["note"] = "stale: kernels changed since that PMC run (current sources_sha16 %s); traffic withheld" % sources_sha16()
         return None, src
     return float(d["_step_hbm_bytes"]), src
+
+
+def pmc_legs_traffic():
+    """{leg: {...}} from the committed per-leg counter passes (tools/gpu_pmc_legs.sh -> profiles/pmc_legs_latest.json): bytes written /
+    fetched per call of every extra leg, cited (not measured by this run) and only when taken on the current kernel sources."""
+    path = os.path.join(ROOT, "profiles", "pmc_legs_latest.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except Exception:
+        return {}, {"file": None, "note": "no committed per-leg PMC summary"}
+    meta = d.get("_meta", {})
+    src = {"file": "profiles/pmc_legs_latest.json", "measured": meta.get("date"), "sources_sha16": meta.get("sources_sha16"),
+           "kind": "citation of separate rocprofv3 --pmc runs (tools/gpu_pmc_legs.sh), not measured by this run"}
+    if meta.get("sources_sha16") != sources_sha16():
+        src["note"] = "stale: kernels changed since those PMC runs (current sources_sha16 %s); traffic withheld" % sources_sha16()
+        return {}, src
+    return {k: v for k, v in d.items() if not k.startswith("_")}, src
 
 
 def self_launch(n_ranks, argv):
@@ -252,6 +271,38 @@ def extra_legs(torch, bhw, B, out, steps):
         legs["C2_bh4_2^20_24bit_graph"] = leg
     except Exception as e:                                       # graph capture unavailable: the per-call figure stands
         legs["C2_bh4_2^20_24bit_graph"] = {"error": repr(e)}
+    # the same 20 windows as THROUGHPUT instead of latency: 20 different buffers, four streams of five calls inside one graph (the
+    # streaming-frame use of configs[3]: independent windows, nothing orders one behind the other but its stream)
+    try:
+        bufs = [torch.empty(1 << 20, dtype=torch.int32, device=out.device) for _ in range(20)]
+        main_st = torch.cuda.Stream()
+        side = [torch.cuda.Stream() for _ in range(4)]
+        for s_ in side:                                          # every stream gets its scratch / lazy state before the capture
+            with torch.cuda.stream(s_):
+                bhw.prepare(p2)
+                bhw.generate(p2, 0, 1 << 20, out=bufs[0])
+        torch.cuda.synchronize()
+        with torch.cuda.stream(main_st):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=main_st):
+                fork = torch.cuda.Event()
+                fork.record(main_st)
+                for si, s_ in enumerate(side):
+                    s_.wait_event(fork)
+                    with torch.cuda.stream(s_):
+                        for k in range(5):
+                            bhw.generate(p2, 0, 1 << 20, out=bufs[si * 5 + k])
+                    join = torch.cuda.Event()
+                    join.record(s_)
+                    main_st.wait_event(join)
+            leg = measure(g.replay, 20 << 20, plan2, note="20 windows into 20 buffers over 4 streams per HIP-graph replay; ms = per window "
+                          "(throughput: windows overlap); the dependent-chain figure is C2_bh4_2^20_24bit_graph", reps=50)
+        leg["ms"] /= 20.0
+        leg["windows_per_s"] = 1.0 / (leg["ms"] * 1e-3)
+        legs["C2_bh4_2^20_24bit_graph_4streams"] = leg
+        del bufs
+    except Exception as e:
+        legs["C2_bh4_2^20_24bit_graph_4streams"] = {"error": repr(e)}
     # BASELINE configs[3]: 1024 frames x BH-4 N = 2^16, 24-bit (one period computed, then store-only replication)
     p4 = bhw.make_params(4, 16, 24)
     o4 = out.view(1024, 1 << 16)
@@ -509,6 +560,18 @@ def main():
             gbs = BYTES_PER_COEFF * count / (cpp_leg["ms_per_step_median"] * 1e-3) / 1e9
             legs["C3_model_cpp"] = {"ms": cpp_leg["ms_per_step_median"], "GB/s": gbs, "frac": gbs / HBM_PEAK_GBS,
                                     "Gsamples_per_s": cpp_leg["Gsamples_per_s"], "plan": cpp_leg["plan"]}
+        # counted bytes beside every leg (profiles/pmc_legs_latest.json, hash-tied to the kernel sources)
+        cited, cited_src = pmc_legs_traffic()
+        alias = {"C2_bh4_2^20_24bit_per_call": "C2_bh4_2^20_24bit", "C2_bh4_2^20_24bit_graph": "C2_bh4_2^20_24bit",
+                 "C2_bh4_2^20_24bit_graph_4streams": "C2_bh4_2^20_24bit"}
+        for name, leg in legs.items():
+            c = cited.get(alias.get(name, name))
+            if isinstance(leg, dict) and "ms" in leg:
+                leg["traffic"] = None if c is None else {"bytes_per_call": c["traffic_bytes_per_call"], "write_bytes": c["write_bytes_per_call"],
+                                                         "read_bytes": c["read_bytes_per_call"], "over_algorithmic": c["traffic_over_algorithmic"]}
+                if c is not None and leg["ms"] > 0:
+                    leg["counted_write_GB/s"] = c["write_bytes_per_call"] / (leg["ms"] * 1e-3) / 1e9
+        legs["_traffic_source"] = cited_src
         step()
 
     total = units_per_step * args.steps

@@ -479,7 +479,7 @@ __global__ __launch_bounds__(tile_wg_of(NB)) __attribute__((amdgpu_waves_per_eu(
     if (win.apply_x == nullptr) {                                    // wave-uniform
         // image (h, j) starts at out + h*H + j*E, a scalar address the lane adds its 32-bit byte offset r * 4 to (saddr stores;
         // the empty asm keeps the compiler from folding the image offset back into a 64-bit vector add per store)
-        auto store_all = [&](auto full_width) {
+        auto store_all = [&](auto full_width, auto through) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -495,12 +495,21 @@ __global__ __launch_bounds__(tile_wg_of(NB)) __attribute__((amdgpu_waves_per_eu(
                         if constexpr (MODE != 2 && decltype(full_width)::value) v = acc_value(acc[b][h][j]);   // W == 32: nothing to wrap
                         else v = final_value(b, h, j);
                         // (plain write-back stores: at agent or system scope -- sc1, sc0 sc1 -- the pass takes 91 us instead of 67, profiles/r04_ab_store_scope.txt)
-                        *reinterpret_cast<int32_t *>(reinterpret_cast<char *>(img) + (rr[b] << 2)) = v;
+                        if constexpr (decltype(through)::value) asm volatile("global_store_dword %0, %1, %2 sc1" :: "v"(rr[b] << 2), "v"(v), "s"(img) : "memory");
+                        else *reinterpret_cast<int32_t *>(reinterpret_cast<char *>(img) + (rr[b] << 2)) = v;
                     }
                 }
         };
-        if (W == 32u) store_all(std::true_type{});
-        else store_all(std::false_type{});
+        // Store scope.  A short window stays dirty in the eight L2s (32 MB together) until the end-of-kernel release writes it back
+        // with nothing else running: windows of up to 2^24 coefficients are stored at agent scope (written through as they are
+        // produced), like the table of the build pass -- 0.0246 -> 0.0239 ms at 2^22, 0.0463 -> 0.0456 at 2^24, a loss from 2^25 on
+        // (0.0576 -> 0.0584).  Long windows keep write-back stores: the L2s evict as they go, and at agent scope the 268 MB of
+        // the headline window take 91 us instead of 67 (profiles/r04_ab_store_scope.txt; through-stores for only the last 1/16 ..
+        // 1/4 of the tiles: +0.6 .. +2.8 us, profiles/r04_ab_tail_wt.txt).
+        const bool wt = cfg.phi_width <= 24u;
+        if (wt) { if (W == 32u) store_all(std::true_type{}, std::true_type{}); else store_all(std::false_type{}, std::true_type{}); }
+        else if (W == 32u) store_all(std::true_type{}, std::false_type{});
+        else store_all(std::false_type{}, std::false_type{});
     } else {
         // Fused apply (emit()): y = (x * w) >> shift.  The x samples of every run of this pass are requested together before the
         // first product (harmonic-major: 24 unit-stride loads in flight per thread; fetched eight at a time, run by run, the pass

@@ -7,6 +7,17 @@
 
 namespace {
 
+// Output stage of the fused kernels: stores at agent scope (sc1), written through the L2 as they are produced.  The windows these
+// kernels take (up to 2^22 coefficients, 16 MB) fit the L2s, and with write-back stores the whole window stayed dirty there until
+// the end-of-kernel release wrote it back -- inside the gap before the next dependent launch: BH-4 2^20 / 24-bit 6.05 -> 5.64 us per
+// window in a 20-call graph, BH-4 2^22 15.3 -> 13.1 us, BH-3 2^22 / 20-bit 10.2 -> 8.1 us (profiles/r04_short_windows_store_scope.txt).
+__device__ __forceinline__ void emit_f(const BhwWinCfg &win, int32_t *__restrict__ out, uint64_t idx, int32_t w)
+{
+    if (win.apply_x) w = (int32_t)(((int64_t)win.apply_x[idx] * (int64_t)w) >> win.apply_shift);
+    asm volatile("global_store_dword %0, %1, off sc1" :: "v"(out + idx), "v"(w) : "memory");
+}
+
+
 // ---------------------------------------------------------------------------------------
 // Fused fold kernel: whole-period work in ONE launch, no table.
 //
@@ -432,7 +443,7 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win, BhwFo
             int32_t v;
             if constexpr (MODE == 2) v = w32_final<BHW_COMBINE_VHDL>(acc[h][j], W, NTERMS);
             else v = (int32_t)((uint32_t)acc[h][j] << (32u - W)) >> (32u - W);         // (win_t)(...) wrap to W bits
-            emit(win, out, (uint64_t)(r + (uint32_t)h * H) + (uint64_t)j * E, v);
+            emit_f(win, out, (uint64_t)(r + (uint32_t)h * H) + (uint64_t)j * E, v);
         }
 }
 
@@ -586,7 +597,7 @@ __global__ __launch_bounds__(256) void k_fold_split(BhwWinCfg win, BhwFoldPlan p
             int32_t v;
             if constexpr (MODE == 2) v = w32_final<BHW_COMBINE_VHDL>(acc[j], W, NTERMS);
             else v = (int32_t)((uint32_t)acc[j] << (32u - W)) >> (32u - W);
-            emit(win, out, (uint64_t)(r + (uint32_t)HH * H) + (uint64_t)j * E, v);
+            emit_f(win, out, (uint64_t)(r + (uint32_t)HH * H) + (uint64_t)j * E, v);
         }
     };
     if (wave == 0u) combine(std::integral_constant<int, 0>{});
@@ -620,7 +631,11 @@ int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg 
     }
     uint64_t total = 0;
     for (uint32_t i = 0; i < n_runs; ++i) total += runs[i].r_end - runs[i].r0;
+    // form of the kernel for this many lanes (bhwp_fold_form, bhw_plan.cpp: the measurements behind the thresholds are quoted there)
+    const int form = bhwp_fold_form(c, w, total);
+    const bool split = form == BHWP_FOLD_SPLIT, narrow = form == BHWP_FOLD_NARROW, lockstep = form == BHWP_FOLD_LOCKSTEP;
     // short launches: one wave per workgroup spreads the few waves over more CUs
+    // (one wave per workgroup for the longer launches of the barrier-free narrow form too: no gain, profiles/r04_short_windows_store_scope.txt)
     const uint32_t block = total <= 64u * 1024u ? 64u : (uint32_t)kFoldBlock;
     uint32_t wg = 0;
     for (uint32_t i = 0; i < n_runs; ++i) {
@@ -636,9 +651,6 @@ int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg 
     if (!wg) return 0;
     const int mode = (w.combine != BHW_COMBINE_HLS) ? 2 : (c.ones_neg ? 1 : 0);
     const dim3 grid(wg), blk(block);
-    // form of the kernel for this many lanes (bhwp_fold_form, bhw_plan.cpp: the measurements behind the thresholds are quoted there)
-    const int form = bhwp_fold_form(c, w, total);
-    const bool split = form == BHWP_FOLD_SPLIT, narrow = form == BHWP_FOLD_NARROW, lockstep = form == BHWP_FOLD_LOCKSTEP;
     plan.k24 = bhwp_fold_k24(c);
     dim3 grid_s(0), blk_s(256);
     if (split) {
