@@ -403,7 +403,7 @@ __device__ __forceinline__ void table_store(void *__restrict__ table, uint32_t i
 }
 
 template <int NITER, int FMT, int THREADS>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8))) void k_table_build_mirror(BhwBuildPlan plan, void *__restrict__ table)
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_table_build_mirror(BhwBuildPlan plan, void *__restrict__ table)
 {
     BHW_STAMP_MIN(0);
 #ifdef BHW_BUILD_STAMPS

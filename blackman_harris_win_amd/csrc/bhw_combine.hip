@@ -526,7 +526,11 @@ __global__ __launch_bounds__(tile_wg_of(NB)) __attribute__((amdgpu_waves_per_eu(
                     const int32_t *ximg = win.apply_x + img_off;
 #pragma unroll
                     for (int b = 0; b < NR; ++b)
-                        if (b >= b0 && b < b1) xv[b][h][j] = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(ximg) + (rr[b] << 2));
+                        // nontemporal: every sample is read once, and streaming 268 MB of them through the L2s / the memory-side cache
+                        // evicts the table lines the gathers live on (0.1698 -> 0.1556 ms for 2^26 samples; nontemporal y stores on
+                        // top: 0.178, profiles/r04_ab_apply_nt.txt)
+                        if (b >= b0 && b < b1)
+                            xv[b][h][j] = __builtin_nontemporal_load(reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(ximg) + (rr[b] << 2)));
                 }
 #pragma unroll
             for (int b = 0; b < NR; ++b)     // all of them in registers before the first store (otherwise each load is sunk next to its use)
@@ -555,7 +559,7 @@ __global__ __launch_bounds__(tile_wg_of(NB)) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) xv[h][j] = win.apply_x[(uint64_t)(rr[b] + (uint32_t)h * H + (uint32_t)j * E)];
+                    for (int j = 0; j < 4; ++j) xv[h][j] = __builtin_nontemporal_load(&win.apply_x[(uint64_t)(rr[b] + (uint32_t)h * H + (uint32_t)j * E)]);
                 asm volatile("" : "+v"(xv[0][0]), "+v"(xv[0][1]), "+v"(xv[0][2]), "+v"(xv[0][3]),
                                   "+v"(xv[1][0]), "+v"(xv[1][1]), "+v"(xv[1][2]), "+v"(xv[1][3]));
 #pragma unroll

@@ -305,7 +305,7 @@ __device__ __forceinline__ int32_t combine_final(int64_t acc, uint32_t W, uint32
 // floor shift, low 32 bits -- so the coefficient vector never round-trips through HBM.
 __device__ __forceinline__ void emit(const BhwWinCfg &win, int32_t *__restrict__ out, uint64_t idx, int32_t w)
 {
-    if (win.apply_x) w = (int32_t)(((int64_t)win.apply_x[idx] * (int64_t)w) >> win.apply_shift);
+    if (win.apply_x) w = (int32_t)(((int64_t)__builtin_nontemporal_load(&win.apply_x[idx]) * (int64_t)w) >> win.apply_shift);   // (x is read once: streamed past the caches)
     out[idx] = w;
 }
 

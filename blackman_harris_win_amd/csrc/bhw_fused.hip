@@ -13,7 +13,7 @@ namespace {
 // window in a 20-call graph, BH-4 2^22 15.3 -> 13.1 us, BH-3 2^22 / 20-bit 10.2 -> 8.1 us (profiles/r04_short_windows_store_scope.txt).
 __device__ __forceinline__ void emit_f(const BhwWinCfg &win, int32_t *__restrict__ out, uint64_t idx, int32_t w)
 {
-    if (win.apply_x) w = (int32_t)(((int64_t)win.apply_x[idx] * (int64_t)w) >> win.apply_shift);
+    if (win.apply_x) w = (int32_t)(((int64_t)__builtin_nontemporal_load(&win.apply_x[idx]) * (int64_t)w) >> win.apply_shift);
     asm volatile("global_store_dword %0, %1, off sc1" :: "v"(out + idx), "v"(w) : "memory");
 }
 

@@ -1,7 +1,7 @@
 """In-process A/B of compile-time variants of libbhw.so (GPU box): every variant is built to its own .so, all are
 loaded side by side and timed interleaved on the same device and clocks, which removes the box-to-box and
 clock-ramp noise of separate bench runs.  usage: python tools/ab_inproc.py "<flags A>" "<flags B>" ...
-env: AB_WIN (7) AB_PW (26) AB_W (32) AB_SIN (0) AB_COMBINE (0) AB_MODEL (0) AB_L (9) AB_ROUNDS (8) AB_INNER (100)
+env: AB_WIN (7) AB_PW (26) AB_W (32) AB_SIN (0) AB_COMBINE (0) AB_MODEL (0) AB_L (9) AB_ROUNDS (8) AB_INNER (100) AB_APPLY AB_PARTS AB_SPLIT
 """
 import ctypes
 import os
@@ -76,7 +76,15 @@ def main():
     p.lut_size = int(os.environ.get("AB_L", "9"))
     parts = int(os.environ.get("AB_PARTS", "0"))          # AB_PARTS=G: time interleaved ownership part 1 of G instead of the whole window
 
+    apply = os.environ.get("AB_APPLY")                    # AB_APPLY=1: time the fused apply y = (x * w) >> 31 instead of the plain window
+    x = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda") if apply else None
+    for L in libs if apply else []:
+        L.bhw_apply_device.argtypes = [ctypes.POINTER(binding.BhwParams), ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+
     def call(L):
+        if apply:
+            return L.bhw_apply_device(ctypes.byref(p), 0, ctypes.c_void_p(st), 0, n, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()), 31)
         if parts:
             return L.bhw_generate_part_device(ctypes.byref(p), 0, ctypes.c_void_p(st), 1, parts, ctypes.c_void_p(out.data_ptr()), None)
         return L.bhw_generate_device(ctypes.byref(p), 0, ctypes.c_void_p(st), 0, n, ctypes.c_void_p(out.data_ptr()))
