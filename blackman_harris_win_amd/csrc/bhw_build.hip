@@ -378,11 +378,11 @@ __device__ __forceinline__ void rot_narrow_block(uint32_t &x, uint32_t &y, int32
 }
 
 // Timeline instrumentation (development builds only, -DBHW_BUILD_STAMPS; tools/build_timeline.py): every workgroup records the
-// 100 MHz wall clock at its phase boundaries -- 8 words per workgroup at g_build_stamps.
+// 100 MHz wall clock at its phase boundaries -- 16 words per workgroup at g_build_stamps.
 #ifdef BHW_BUILD_STAMPS
 __device__ unsigned long long *g_build_stamps = nullptr;
-#define BHW_STAMP(i) do { if (g_build_stamps && (threadIdx.x & 63u) == 0u) atomicMax(&g_build_stamps[blockIdx.x * 8u + (i)], (unsigned long long)wall_clock64()); } while (0)
-#define BHW_STAMP_MIN(i) do { if (g_build_stamps && threadIdx.x == 0u) g_build_stamps[blockIdx.x * 8u + (i)] = (unsigned long long)wall_clock64(); } while (0)
+#define BHW_STAMP(i) do { if (g_build_stamps && (threadIdx.x & 63u) == 0u) atomicMax(&g_build_stamps[blockIdx.x * 16u + (i)], (unsigned long long)wall_clock64()); } while (0)
+#define BHW_STAMP_MIN(i) do { if (g_build_stamps && threadIdx.x == 0u) g_build_stamps[blockIdx.x * 16u + (i)] = (unsigned long long)wall_clock64(); } while (0)
 #else
 #define BHW_STAMP(i) do { } while (0)
 #define BHW_STAMP_MIN(i) do { } while (0)
@@ -410,8 +410,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
     if (g_build_stamps && threadIdx.x == 0u) {                       // where this workgroup runs: HW_ID (CU / SH / SE) and the XCD
         uint32_t hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
-        g_build_stamps[blockIdx.x * 8u + 6u] = hw;
-        g_build_stamps[blockIdx.x * 8u + 7u] = xcc;
+        g_build_stamps[blockIdx.x * 16u + 6u] = hw;
+        g_build_stamps[blockIdx.x * 16u + 7u] = xcc;
     }
 #endif
     static_assert(FMT == 2 || FMT == 3, "residual / nibble entries");
@@ -431,7 +431,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
     constexpr uint32_t kWorkMax = 8 * gpw;           // images to run as chains of their own (expected ~0.6 per group)
     __shared__ uint32_t work_n;
     __shared__ uint32_t work_u[kWorkMax];
+    // (all kernel arguments requested in one batch of scalar loads up front: measured, no gain -- 0.0966 / 0.0977 ms; the serial start is
+    // bound by the dependent 64-bit rotations of the prefix and head chains, profiles/r04_build_timeline_final.txt)
     if (threadIdx.x < 32) lut_s[threadIdx.x] = plan.lut[threadIdx.x];
+#ifdef BHW_BUILD_STAMPS
+    if (g_build_stamps && threadIdx.x == 0u) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g_build_stamps[blockIdx.x * 16u + 8u] = (unsigned long long)wall_clock64() | (plan.entries & 0u); }   // kernel arguments have arrived
+#endif
     constexpr int n_iter = NITER;
     constexpr int KS = NITER - kMirrorTail;                     // image state taken at this rotation
     const uint32_t s = plan.z_shl;
@@ -466,6 +471,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
             }
             tail_p[zi] = (uint8_t)p;
         }
+        BHW_STAMP(9);                                                // tail tables filled
     }
     // (no barrier here: the tail tables and lut_s are first read in phase 2, behind the two barriers below)
 
@@ -501,6 +507,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 hs[w][t] = (int32_t)(y >> plan.out_shr);
             }
         }
+        BHW_STAMP(10);                                               // head chains done
     }
 
     // ---- phase 1: shared prefix of each 64-leaf group (never past KS: the image state is taken there) ----
@@ -540,6 +547,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
         gz[threadIdx.x] = zf;
         gk[threadIdx.x] = k;
         gflag[threadIdx.x] = zero0 | (narrow || hi ? 2u : 0u) | (hi ? 4u : 0u);
+        BHW_STAMP(11);                                               // prefixes done
     }
     BHW_STAMP(1);                                                    // last wave to reach the first barrier
     __syncthreads();

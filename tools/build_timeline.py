@@ -32,12 +32,12 @@ def main():
         for _ in range(300):                                          # format verdicts + clock ramp
             assert L.bhw_generate_device(ctypes.byref(p), 0, ctypes.c_void_p(st), 0, n, ctypes.c_void_p(out.data_ptr())) == 0
         torch.cuda.synchronize()
-        stamps = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda")
+        stamps = torch.zeros(4096 * 16, dtype=torch.int64, device="cuda")
         assert L.bhw_dbg_build_stamps(ctypes.c_void_p(stamps.data_ptr())) == 0
         L.bhw_generate_device(ctypes.byref(p), 0, ctypes.c_void_p(st), 0, n, ctypes.c_void_p(out.data_ptr()))
         torch.cuda.synchronize()
         L.bhw_dbg_build_stamps(None)
-        t = stamps.cpu().numpy().reshape(-1, 8)
+        t = stamps.cpu().numpy().reshape(-1, 16)
         t = t[t[:, 0] != 0].astype(np.float64) * 0.01               # 100 MHz -> us
         t0 = t[:, 0].min()
         rel = t - t0
@@ -47,6 +47,10 @@ def main():
         print("[%s] %d workgroups, us relative to the first workgroup's start" % (flags, len(t)))
         print("  start of a workgroup              ", q(rel[:, 0]))
         print("  serial start (to the 1st barrier) ", q(t[:, 1] - t[:, 0]))
+        print("    ... kernel arguments arrived     ", q(t[:, 8] - t[:, 0]))
+        print("    ... tail tables filled           ", q(t[:, 9] - t[:, 0]))
+        print("    ... head chains done             ", q(t[:, 10] - t[:, 0]))
+        print("    ... group prefixes done          ", q(t[:, 11] - t[:, 0]))
         print("  records (to the 2nd barrier)      ", q(t[:, 2] - t[:, 1]))
         print("  groups, first wave done           ", q(t[:, 3] - t[:, 2]))
         print("  groups, last wave done            ", q(t[:, 4] - t[:, 2]))
