@@ -549,10 +549,11 @@ int bhwp_part_checks(const bhw_params *p, uint32_t part, uint32_t n_parts)
 }
 
 // Strategy of one ownership part.  Fused: chains = lanes x (chains per lane), no table.  Table: the full first-quadrant table (it
-// does not shrink with the part) + this part's tiles.  Measured per part (BH-7 2^26 / 32-bit, profiles/r03_small_windows_and_parts.json):
-// table 0.080 / 0.065 / 0.057 ms at 2 / 4 / 8 parts, fused 0.094 / 0.053 ms at 4 / 8: the fused kernel wins once the part's own
-// chains (9/8 per owned coefficient) are no more than the table's (between 4 and 8 parts).  (The 0.1195 ms that file shows for
-// AUTO at one part against 0.1123 for the same table plan was the first timing after a run of short kernels -- clocks, not the plan.)
+// does not shrink with the part) + this part's tiles.  Measured per part (BH-7 2^26 / 32-bit, profiles/r04_small_windows_and_parts.json):
+// table 0.068 / 0.055 / 0.049 ms at 2 / 4 / 8 parts, fused 0.092 / 0.051 ms at 4 / 8 -- the build pass got 20 % faster this round and the
+// crossover moved out: the fused kernel is taken once the part's own chains (9/8 per owned coefficient) are at most HALF the
+// table's (more than 8 parts of this window).  (Round 3's file showed 0.1195 ms for AUTO at one part against 0.1123 for the same
+// table plan: the first timing after a run of short kernels -- clocks, not the plan; the tool now ramps again before that section.)
 bool bhwp_part_fused(const bhw_params *p, const BhwCordicCfg &c, const BhwFoldRun *runs, int n_runs, uint32_t tile_count, uint32_t requested, int *rc)
 {
     *rc = BHW_OK;
@@ -565,7 +566,7 @@ bool bhwp_part_fused(const bhw_params *p, const BhwCordicCfg &c, const BhwFoldRu
     bool fused;
     if (requested == BHW_ALGO_FUSED) fused = fused_ok;
     else if (requested == BHW_ALGO_TABLE) fused = !table_ok;
-    else fused = fused_ok && (!table_ok || chains_fused <= bhwp_table_entries(c));
+    else fused = fused_ok && (!table_ok || 2 * chains_fused <= bhwp_table_entries(c));
     if (fused && !fused_ok) *rc = bhwp_fail(BHW_ERR_UNSUPPORTED, "no kernel produces this part (CORDIC state beyond 34 bits and no tile plan)");
     if (!fused && !table_ok) *rc = bhwp_fail(BHW_ERR_UNSUPPORTED, "the table strategy produces whole tiles only and this window has no tile plan");
     return fused;
