@@ -71,6 +71,11 @@ __global__ __launch_bounds__(kBuildThreads) void k_prerot_sweep(BhwPrerotCfg c, 
 {
     __shared__ int64_t gx[kGroupsPerWg], gy[kGroupsPerWg], gz[kGroupsPerWg];
     __shared__ int32_t gk[kGroupsPerWg];
+    // The per-leaf stages read their ROM word from shared memory (a broadcast read) once there are more than 26 of them: 32 64-bit
+    // words as scalar kernel arguments are 64 SGPRs, and the instances from 27 stages on used to spill 2 .. 12 of them.
+    constexpr bool kLutLds = NITER > 26;
+    __shared__ int64_t lut_s[kLutLds ? 32 : 1];
+    if (kLutLds && threadIdx.x >= 64u && threadIdx.x < 96u) lut_s[threadIdx.x - 64u] = c.lut[threadIdx.x - 64u];
     const uint32_t PW = c.phi_width, zs = c.dwph - PW;
     const uint32_t group0 = blockIdx.x * kGroupsPerWg, n_groups = 1u << (PW - 6);
     constexpr int kmax = NITER < kPrefixMax ? NITER : kPrefixMax;
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_prerot_sweep(BhwPrerotCfg c, 
         int64_t x = gx[gi], y = gy[gi];
         int64_t z = gz[gi] + ((int64_t)lane << zs);
         const int k0 = __builtin_amdgcn_readfirstlane(gk[gi]);
-#define BHW_POST(II) if constexpr (NITER > II) { if (II >= kmax || II >= k0) prerot_step<II>(x, y, z, c.lut[II], II + 1 == NITER); }
+#define BHW_POST(II) if constexpr (NITER > II) { if (II >= kmax || II >= k0) prerot_step<II>(x, y, z, kLutLds ? lut_s[II] : c.lut[II], II + 1 == NITER); }
         BHW_POST(0) BHW_POST(1) BHW_POST(2) BHW_POST(3) BHW_POST(4) BHW_POST(5) BHW_POST(6) BHW_POST(7)
         BHW_POST(8) BHW_POST(9) BHW_POST(10) BHW_POST(11) BHW_POST(12) BHW_POST(13) BHW_POST(14) BHW_POST(15)
         BHW_POST(16) BHW_POST(17) BHW_POST(18) BHW_POST(19) BHW_POST(20) BHW_POST(21) BHW_POST(22) BHW_POST(23)
