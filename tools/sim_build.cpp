@@ -12,7 +12,7 @@
 // Every entry of the first-quadrant table is compared with the plain chain (the rotation loop of
 // hls/windows/win_function.cpp:110-125 | cpp/cordic_sincos.cpp:49-63 | src/cordic_dds.vhd:197-213).
 // Test infrastructure / design evidence only: nothing here is linked into the product.
-//   usage: sim_build <model 0 hls | 1 cpp | 2 vhdl> <PW> <W> [precision]     (exit code 0 = every entry identical)
+//   usage: sim_build <model 0 hls | 1 cpp | 2 vhdl> <PW> <W> [precision [tail rotations 6 | 7]]     (exit code 0 = every entry identical)
 #include <quadmath.h>
 
 #include <cstdint>
@@ -62,7 +62,9 @@ int main(int argc, char **argv)
     else { const int Wi = W + P; for (int i = 0; i + 1 < W; ++i) c.lut[i] = T4[i] >> (49 - Wi); c.x0 = G47 >> (49 - Wi); c.n_iter = W - 1; c.z_shl = W - PW + P; c.out_shr = P; }
     if (c.z_shl < 0 || (model == 0 ? PW - 1 >= W : model == 1 ? PW - 1 >= W : PW >= W)) { fprintf(stderr, "z_shr != 0: not a mirror-kernel configuration\n"); return 2; }
     c.E = 1u << (PW - 2);
-    const int N = c.n_iter, TAIL = 6, KS = N - TAIL, PREFIX_MAX = 20;
+    const int N = c.n_iter, TAIL = argc > 5 ? atoi(argv[5]) : 6, KS = N - TAIL, PREFIX_MAX = 20;
+    if (TAIL != 6 && TAIL != 7) { fprintf(stderr, "tail of 6 or 7 rotations\n"); return 2; }
+    const int NV = 1 << TAIL, NP = 1 << TAIL, MARGIN = 2 << TAIL;     // rows / patterns of D; the tail moves x by less than MARGIN
     const int kcap = KS < PREFIX_MAX ? KS : PREFIX_MAX;
     const uint32_t E = c.E;
     const int s = c.z_shl;
@@ -78,7 +80,7 @@ int main(int argc, char **argv)
     }
 
     // tail tables: pattern of z_KS (range [-ZB, ZB)), D[p][v]
-    const int ZB = 256;
+    const int ZB = 4 << TAIL;                                                // |z_KS| < ZB (checked per lane below)
     std::vector<uint16_t> Pz(2 * ZB);
     for (int zi = 0; zi < 2 * ZB; ++zi) {
         int64_t z = zi - ZB;
@@ -89,12 +91,12 @@ int main(int argc, char **argv)
         }
         Pz[zi] = (uint16_t)p;
     }
-    int8_t D[64][65];
-    for (unsigned p = 0; p < 64; ++p)
-        for (int v = 0; v < 65; ++v) {
+    std::vector<std::vector<int16_t>> D(NP, std::vector<int16_t>(NV + 1));
+    for (unsigned p = 0; p < (unsigned)NP; ++p)
+        for (int v = 0; v <= NV; ++v) {
             int d = 0;
             for (int j = 0; j < TAIL; ++j) d += ((p >> j) & 1u) ? -(v >> j) : (v >> j);    // sigma = +1 when z >= 0
-            D[p][v] = (int8_t)d;
+            D[p][v] = (int16_t)d;
         }
 
     std::vector<int32_t> gc(E, INT32_MIN), gs(E, INT32_MIN);
@@ -154,7 +156,7 @@ int main(int argc, char **argv)
             if (narrow) {
                 if (x - bias < 0 || y < 0 || x - bias >= ((int64_t)1 << 32) || y >= LIM) { fprintf(stderr, "narrow range violated at KS\n"); return 1; }
                 const uint32_t lowm = (1u << KS) - 1u;
-                const bool ok = (((uint32_t)(x - bias) + 128u) & lowm) >= 256u && (((uint32_t)y + 128u) & lowm) >= 256u &&
+                const bool ok = (((uint32_t)(x - bias) + (uint32_t)MARGIN) & lowm) >= 2u * (uint32_t)MARGIN && (((uint32_t)y + (uint32_t)MARGIN) & lowm) >= 2u * (uint32_t)MARGIN &&
                                 (uint64_t)(z + ZB) < (uint64_t)(2 * ZB);
                 if (!ok) { wave_unsafe = true; ++unsafe_lanes; }
             }
@@ -168,7 +170,7 @@ int main(int argc, char **argv)
             if (narrow && !wave_unsafe) {
                 const uint32_t xu = (uint32_t)(x - bias);
                 const uint32_t xx = (xu >> KS) + (uint32_t)(bias >> KS), yy = (uint32_t)y >> KS;
-                if (xx > 64 || yy > 63) { fprintf(stderr, "tail operand out of range\n"); return 1; }
+                if (xx > (uint32_t)NV || yy >= (uint32_t)NV) { fprintf(stderr, "tail operand out of range\n"); return 1; }
                 const unsigned p = Pz[z + ZB], p2 = Pz[-z + ZB];
                 const uint32_t bo = (uint32_t)(bias >> c.out_shr);
                 oc = (int32_t)(((xu - (uint32_t)(int32_t)D[p][yy]) >> c.out_shr) + bo);
