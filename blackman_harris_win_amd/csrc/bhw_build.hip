@@ -313,12 +313,14 @@ __device__ __forceinline__ void rot_narrow(uint32_t &x, uint32_t &y, int32_t &z,
 // exactly: one more VOP2 per rotation (a literal operand), everything else is the same code.  (Those 0.7 % of the groups all sit
 // in the first four workgroups; on the 64-bit path they kept the whole pass waiting 6 us for those four,
 // profiles/r04_build_timeline.txt.)
-template <int KA, int NITER, bool HI>
-__device__ __forceinline__ void rot_narrow_block(uint32_t &x, uint32_t &y, int32_t &z, uint32_t &zacc, const uint32_t *lut, int e)
+template <int KA, int NITER>
+__device__ __forceinline__ void rot_narrow_block(uint32_t &x, uint32_t &y, int32_t &z, uint32_t &zacc, const uint32_t *lut, int e, uint32_t hi)
 {
+    // Both forms in ONE statement behind a scalar branch on `hi` (labels 0 .. 10 plain, 20 .. 30 biased): as two statements in an
+    // if / else the register allocator gave them different registers and joined them with four v_mov per group.
     uint32_t a, b;
-#define BHW_ROT_I(i, HI_ADD)                                                                                           \
-    #i ":\n\t"                                                                                                          \
+#define BHW_ROT_I(lbl, i, HI_ADD)                                                                                       \
+    #lbl ":\n\t"                                                                                                        \
     "v_lshrrev_b32 %[a], %[k" #i "], %[y]\n\t"                                                                          \
     "v_lshrrev_b32 %[b], %[k" #i "], %[x]\n\t"                                                                          \
     HI_ADD                                                                                                             \
@@ -332,49 +334,44 @@ __device__ __forceinline__ void rot_narrow_block(uint32_t &x, uint32_t &y, int32
     "v_add_u32 %[y], %[y], %[b]\n\t"                                                                                    \
     "v_sub_u32 %[z], %[z], %[l" #i "]\n\t"                                                                              \
     "s_mov_b64 exec, -1\n"
-#define BHW_ROT_PLAIN(i) BHW_ROT_I(i, "")
-#define BHW_ROT_HI(i) BHW_ROT_I(i, "v_add_u32 %[b], %[c" #i "], %[b]\n\t")
-#define BHW_ROT_DISPATCH                                                                                               \
-                 "s_cmp_lt_i32 %[e], 1\n\ts_cbranch_scc1 0f\n\t"                                                       \
-                 "s_cmp_eq_u32 %[e], 1\n\ts_cbranch_scc1 1f\n\t"                                                       \
-                 "s_cmp_eq_u32 %[e], 2\n\ts_cbranch_scc1 2f\n\t"                                                       \
-                 "s_cmp_eq_u32 %[e], 3\n\ts_cbranch_scc1 3f\n\t"                                                       \
-                 "s_cmp_eq_u32 %[e], 4\n\ts_cbranch_scc1 4f\n\t"                                                       \
-                 "s_cmp_eq_u32 %[e], 5\n\ts_cbranch_scc1 5f\n\t"                                                       \
-                 "s_cmp_eq_u32 %[e], 6\n\ts_cbranch_scc1 6f\n\t"                                                       \
-                 "s_cmp_eq_u32 %[e], 7\n\ts_cbranch_scc1 7f\n\t"                                                       \
-                 "s_cmp_eq_u32 %[e], 8\n\ts_cbranch_scc1 8f\n\t"                                                       \
-                 "s_cmp_eq_u32 %[e], 9\n\ts_cbranch_scc1 9f\n\t"                                                       \
+#define BHW_ROT_PLAIN(i) BHW_ROT_I(i, i, "")
+#define BHW_ROT_HI(i) BHW_ROT_I(2##i, i, "v_add_u32 %[b], %[c" #i "], %[b]\n\t")
+#define BHW_ROT_DISPATCH(P)                                                                                            \
+                 "s_cmp_lt_i32 %[e], 1\n\ts_cbranch_scc1 " #P "0f\n\t"                                                 \
+                 "s_cmp_eq_u32 %[e], 1\n\ts_cbranch_scc1 " #P "1f\n\t"                                                 \
+                 "s_cmp_eq_u32 %[e], 2\n\ts_cbranch_scc1 " #P "2f\n\t"                                                 \
+                 "s_cmp_eq_u32 %[e], 3\n\ts_cbranch_scc1 " #P "3f\n\t"                                                 \
+                 "s_cmp_eq_u32 %[e], 4\n\ts_cbranch_scc1 " #P "4f\n\t"                                                 \
+                 "s_cmp_eq_u32 %[e], 5\n\ts_cbranch_scc1 " #P "5f\n\t"                                                 \
+                 "s_cmp_eq_u32 %[e], 6\n\ts_cbranch_scc1 " #P "6f\n\t"                                                 \
+                 "s_cmp_eq_u32 %[e], 7\n\ts_cbranch_scc1 " #P "7f\n\t"                                                 \
+                 "s_cmp_eq_u32 %[e], 8\n\ts_cbranch_scc1 " #P "8f\n\t"                                                 \
+                 "s_cmp_eq_u32 %[e], 9\n\ts_cbranch_scc1 " #P "9f\n\t"
+    constexpr int S = NITER - 1 - KA;                      // B >> (KA + i) = 2^(S - i)
+    static_assert(S >= 9 && S <= 30, "bias shifts");
+    asm volatile("s_cmp_lg_u32 %[hi], 0\n\ts_cbranch_scc1 100f\n\t"
+                 BHW_ROT_DISPATCH()
                  "s_branch 10f\n"
-#define BHW_ROT_OPERANDS                                                                                               \
-                 : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [za] "+v"(zacc), [a] "=&v"(a), [b] "=&v"(b)                  \
-                 : [e] "s"(e), [l0] "s"(lut[KA]), [l1] "s"(lut[KA + 1]), [l2] "s"(lut[KA + 2]), [l3] "s"(lut[KA + 3]), [l4] "s"(lut[KA + 4]), \
-                   [l5] "s"(lut[KA + 5]), [l6] "s"(lut[KA + 6]), [l7] "s"(lut[KA + 7]), [l8] "s"(lut[KA + 8]), [l9] "s"(lut[KA + 9]), \
-                   [k0] "n"(KA), [k1] "n"(KA + 1), [k2] "n"(KA + 2), [k3] "n"(KA + 3), [k4] "n"(KA + 4), [k5] "n"(KA + 5), [k6] "n"(KA + 6), \
-                   [k7] "n"(KA + 7), [k8] "n"(KA + 8), [k9] "n"(KA + 9)
-    if constexpr (HI) {
-        constexpr int S = NITER - 1 - KA;                  // B >> (KA + i) = 2^(S - i)
-        static_assert(S >= 9 && S <= 30, "bias shifts");
-        asm volatile(BHW_ROT_DISPATCH
-                     BHW_ROT_HI(0) BHW_ROT_HI(1) BHW_ROT_HI(2) BHW_ROT_HI(3) BHW_ROT_HI(4) BHW_ROT_HI(5) BHW_ROT_HI(6) BHW_ROT_HI(7) BHW_ROT_HI(8) BHW_ROT_HI(9)
-                     "10:"
-                     BHW_ROT_OPERANDS,
-                       [c0] "n"(1 << S), [c1] "n"(1 << (S - 1)), [c2] "n"(1 << (S - 2)), [c3] "n"(1 << (S - 3)), [c4] "n"(1 << (S - 4)),
-                       [c5] "n"(1 << (S - 5)), [c6] "n"(1 << (S - 6)), [c7] "n"(1 << (S - 7)), [c8] "n"(1 << (S - 8)), [c9] "n"(1 << (S - 9))
-                     : "vcc", "scc");
-    } else {
-        asm volatile(BHW_ROT_DISPATCH
-                     BHW_ROT_PLAIN(0) BHW_ROT_PLAIN(1) BHW_ROT_PLAIN(2) BHW_ROT_PLAIN(3) BHW_ROT_PLAIN(4) BHW_ROT_PLAIN(5) BHW_ROT_PLAIN(6) BHW_ROT_PLAIN(7)
-                     BHW_ROT_PLAIN(8) BHW_ROT_PLAIN(9)
-                     "10:"
-                     BHW_ROT_OPERANDS
-                     : "vcc", "scc");
-    }
+                 BHW_ROT_PLAIN(0) BHW_ROT_PLAIN(1) BHW_ROT_PLAIN(2) BHW_ROT_PLAIN(3) BHW_ROT_PLAIN(4) BHW_ROT_PLAIN(5) BHW_ROT_PLAIN(6) BHW_ROT_PLAIN(7)
+                 BHW_ROT_PLAIN(8) BHW_ROT_PLAIN(9)
+                 "10:\n\ts_branch 200f\n"
+                 "100:\n\t"
+                 BHW_ROT_DISPATCH(2)
+                 "s_branch 200f\n"
+                 BHW_ROT_HI(0) BHW_ROT_HI(1) BHW_ROT_HI(2) BHW_ROT_HI(3) BHW_ROT_HI(4) BHW_ROT_HI(5) BHW_ROT_HI(6) BHW_ROT_HI(7) BHW_ROT_HI(8) BHW_ROT_HI(9)
+                 "200:"
+                 : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [za] "+v"(zacc), [a] "=&v"(a), [b] "=&v"(b)
+                 : [e] "s"(e), [hi] "s"(hi), [l0] "s"(lut[KA]), [l1] "s"(lut[KA + 1]), [l2] "s"(lut[KA + 2]), [l3] "s"(lut[KA + 3]), [l4] "s"(lut[KA + 4]),
+                   [l5] "s"(lut[KA + 5]), [l6] "s"(lut[KA + 6]), [l7] "s"(lut[KA + 7]), [l8] "s"(lut[KA + 8]), [l9] "s"(lut[KA + 9]),
+                   [k0] "n"(KA), [k1] "n"(KA + 1), [k2] "n"(KA + 2), [k3] "n"(KA + 3), [k4] "n"(KA + 4), [k5] "n"(KA + 5), [k6] "n"(KA + 6),
+                   [k7] "n"(KA + 7), [k8] "n"(KA + 8), [k9] "n"(KA + 9),
+                   [c0] "n"(1 << S), [c1] "n"(1 << (S - 1)), [c2] "n"(1 << (S - 2)), [c3] "n"(1 << (S - 3)), [c4] "n"(1 << (S - 4)),
+                   [c5] "n"(1 << (S - 5)), [c6] "n"(1 << (S - 6)), [c7] "n"(1 << (S - 7)), [c8] "n"(1 << (S - 8)), [c9] "n"(1 << (S - 9))
+                 : "vcc", "scc");
 #undef BHW_ROT_I
 #undef BHW_ROT_PLAIN
 #undef BHW_ROT_HI
 #undef BHW_ROT_DISPATCH
-#undef BHW_ROT_OPERANDS
 }
 
 // Timeline instrumentation (development builds only, -DBHW_BUILD_STAMPS; tools/build_timeline.py): every workgroup records the
@@ -394,12 +391,13 @@ __device__ unsigned long long *g_build_stamps = nullptr;
 // per window; sc0 alone changes nothing; nontemporal stores make the build as fast but leave the table out of the memory-side
 // cache, and the combine pass then takes 94 us instead of 67).  The combine pass runs on other XCDs and reads the table through
 // their own L2s, so device scope is also what the data needs.
-template <typename T>
-__device__ __forceinline__ void table_store(void *__restrict__ table, uint32_t idx, T v)
+// (scalar table base + 32-bit byte offset: the saddr form, no 64-bit vector add per store; the value's upper bits are ignored by
+// the narrow store, so the caller need not mask them)
+template <int BYTES>
+__device__ __forceinline__ void table_store(void *__restrict__ table, uint32_t idx, uint32_t v)
 {
-    T *ptr = reinterpret_cast<T *>(table) + idx;
-    if constexpr (sizeof(T) == 1) asm volatile("global_store_byte %0, %1, off sc1" :: "v"(ptr), "v"((uint32_t)v) : "memory");
-    else asm volatile("global_store_short %0, %1, off sc1" :: "v"(ptr), "v"((uint32_t)v) : "memory");
+    if constexpr (BYTES == 1) asm volatile("global_store_byte %0, %1, %2 sc1" :: "v"(idx), "v"(v), "s"(table) : "memory");
+    else asm volatile("global_store_short %0, %1, %2 sc1" :: "v"(idx << 1), "v"(v), "s"(table) : "memory");
 }
 
 template <int NITER, int FMT, int THREADS>
@@ -582,10 +580,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
         const int32_t dc = c - p.x, ds = sn - p.y;
         if constexpr (FMT == 3) {
             if (plan.check_flag && !(fits_bits(dc, 4) && fits_bits(ds, 4))) atomicOr(plan.check_flag, 1u);
-            table_store<uint8_t>(table, idx, (uint8_t)(((uint32_t)dc & 0xFu) | (((uint32_t)ds & 0xFu) << 4)));
+            table_store<1>(table, idx, ((uint32_t)dc & 0xFu) | ((uint32_t)ds << 4));              // bits 8.. are not stored
         } else {
             if (plan.check_flag && !(fits_bits(dc, 8) && fits_bits(ds, 8))) atomicOr(plan.check_flag, 1u);
-            table_store<uint16_t>(table, idx, (uint16_t)(((uint32_t)dc & 0xFFu) | (((uint32_t)ds & 0xFFu) << 8)));
+            table_store<2>(table, idx, ((uint32_t)dc & 0xFFu) | ((uint32_t)ds << 8));           // bits 16.. are not stored
         }
     };
 
@@ -638,8 +636,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #undef BHW_NARROW
             }
             const bool hi = (gf & 4u) != 0u;                          // scalar: x holds x - 2^(NITER-1)
-            if (hi) rot_narrow_block<KA, NITER, true>(x, y, z, zacc, plan.lut, k0 - KA);
-            else rot_narrow_block<KA, NITER, false>(x, y, z, zacc, plan.lut, k0 - KA);
+            rot_narrow_block<KA, NITER>(x, y, z, zacc, plan.lut, k0 - KA, hi ? 1u : 0u);
             zmask = __builtin_amdgcn_ballot_w64(zacc == 0u);
             const uint32_t xrow6 = hi ? (1u << (NITER - 1 - KS + 6)) : 0u;   // (B >> KS) << 6: the bias in the tail table's row index
             const uint32_t bias_out = hi ? ((1u << (NITER - 1)) >> plan.out_shr) : 0u;   // B >> out_shr

@@ -35,7 +35,7 @@ def main():
         for _ in range(300):
             assert L.bhw_generate_device(ctypes.byref(p), 0, ctypes.c_void_p(st), 0, n, ctypes.c_void_p(out.data_ptr())) == 0
         torch.cuda.synchronize()
-        stamps = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda").view(-1, 8)
+        stamps = torch.zeros(16384 * 8, dtype=torch.int64, device="cuda").view(-1, 8)
         stamps[:, 0] = (1 << 62)
         stamps[:, 2] = (1 << 62)
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
