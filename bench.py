@@ -307,7 +307,7 @@ def extra_legs(torch, bhw, B, out, steps):
     p4 = bhw.make_params(4, 16, 24)
     o4 = out.view(1024, 1 << 16)
     legs["C4_1024x_bh4_2^16_24bit"] = measure(lambda: bhw.generate_batched(p4, 1024, out=o4), n26,
-                                              lambda: B.describe_plan(p4, 0, 1 << 16, B.ALGO_AUTO) + " + k_replicate16")
+                                              lambda: B.describe_plan(p4, 0, 1 << 16, B.ALGO_AUTO) + " -- batched: the one launch writes all 1024 frames")
     # phase bits dropped (models A / C at PHASE_WIDTH > DATA_WIDTH): run-length kernel
     pn = bhw.make_params(WIN, PHI_WIDTH, 16, model=B.MODEL_CPP)
     legs["bh7_2^26_16bit_cpp"] = measure(lambda: bhw.generate(pn, 0, n26, out=out), n26, lambda: B.describe_plan(pn, 0, n26, B.ALGO_AUTO))

@@ -370,6 +370,25 @@ int bhw_generate_batched_device(const bhw_params *p, int device, void *hip_strea
     if (!frames) return BHW_OK;
     if (!d_out) return fail(BHW_ERR_BADARG, "d_out is NULL");
     const uint64_t N = 1ull << p->phi_width;
+    if (frames > 1 && p->sin_type == BHW_SIN_CORDIC) {
+        // a period the fused kernel takes, up to 2^19 coefficients: ONE launch computes it and writes every frame -- no second kernel
+        // reading frame 0 back.  1024 x 2^16 (BASELINE configs[3]) 0.0430 -> 0.0408 ms; 0.0410 - 0.0419 against 0.0427 - 0.0439 for
+        // periods of 2^14 .. 2^19; at 2^20 the rows' repeated computation is no longer hidden (0.0468 against 0.0441) and the old
+        // path stays (profiles/r04_ab_batched_one_launch.txt)
+        BhwCordicCfg c;
+        bhwp_resolve_cordic(p, c);
+        BhwWinCfg w;
+        bhwp_resolve_window(p, w);
+        if (p->phi_width <= 19 && bhwp_pick_algo(p, c, w, 0, N, BHW_ALGO_AUTO) == BHW_ALGO_FUSED && bhwp_fold_form(c, w, N >> 3) != BHWP_FOLD_SPLIT) {
+            if (!device_ok(device)) return fail(BHW_ERR_HIP, "no usable HIP device %d (this library has no CPU path)", device);
+            DeviceGuard guard(device);
+            if (guard.err != hipSuccess) return fail_hip(guard.err, "hipSetDevice");
+            BhwLaunch l{device, hip_stream};
+            const BhwFoldRun ring{0u, 1u << (p->phi_width - 3)};
+            const int e = bhwk_fold_direct(l, c, w, &ring, 1, d_out, frames);
+            return e ? fail_hip(e, "fused batched launch") : BHW_OK;
+        }
+    }
     // frame 0 is generated in place, then replicated into frames 1..frames-1
     rc = generate_impl(p, device, hip_stream, 0, N, d_out, nullptr);
     if (rc || frames == 1) return rc;

@@ -44,7 +44,7 @@ struct BhwFoldPlan {
     uint32_t fast_mul, k24;                  // 1: every harmonic weight below 2^(W-3): one-instruction products (tile_harmonic FAST);
                                              // k24: first rotation the sign-product form of the narrow kernel is valid at (rot_mad24)
     uint32_t run0_r0, run0_end;              // = r0[0], r_end[0], next to the other scalars: a one-run launch reads one block of arguments
-    uint32_t block, pad1;                    // threads per workgroup of this launch (k_fold_direct: 64 or 256)
+    uint32_t block, frames;                  // threads per workgroup of this launch (k_fold_direct: 64 or 256); identical frames to write (>= 1)
     uint32_t r0[kFoldRunsMax];               // first ring index of each run
     uint32_t r_end[kFoldRunsMax];            // one past its last
     uint32_t wg_first[kFoldRunsMax + 1];     // first workgroup of each run; [n_runs] = grid size
@@ -436,15 +436,34 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win, BhwFo
 #undef BHW_FD_TERM
 #undef BHW_FD_HARMONIC
     if (r >= r_end) return;
+    int32_t vout[2][4];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            int32_t v;
-            if constexpr (MODE == 2) v = w32_final<BHW_COMBINE_VHDL>(acc[h][j], W, NTERMS);
-            else v = (int32_t)((uint32_t)acc[h][j] << (32u - W)) >> (32u - W);         // (win_t)(...) wrap to W bits
-            emit_f(win, out, (uint64_t)(r + (uint32_t)h * H) + (uint64_t)j * E, v);
+            if constexpr (MODE == 2) vout[h][j] = w32_final<BHW_COMBINE_VHDL>(acc[h][j], W, NTERMS);
+            else vout[h][j] = (int32_t)((uint32_t)acc[h][j] << (32u - W)) >> (32u - W);   // (win_t)(...) wrap to W bits
         }
+    if (plan.frames <= 1u) {                                              // scalar
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) emit_f(win, out, (uint64_t)(r + (uint32_t)h * H) + (uint64_t)j * E, vout[h][j]);
+        return;
+    }
+    // Batched identical frames (bhw_generate_batched_device: the coefficient stream is periodic, src/bh_win_7term.vhd:92-97): the
+    // lane's eight coefficients go into every frame of this workgroup row's share -- the frames are divided over gridDim.y, each
+    // row computing the period again (a few microseconds of latency) instead of a second kernel reading it back.  The whole batch
+    // is far larger than the L2s: plain write-back stores.
+    const uint32_t per = (plan.frames + gridDim.y - 1u) / gridDim.y;
+    const uint32_t f0 = blockIdx.y * per, f1 = f0 + per < plan.frames ? f0 + per : plan.frames;
+    for (uint32_t f = f0; f < f1; ++f) {
+        int32_t *frame = out + ((uint64_t)f << plan.phi_width);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) frame[(uint64_t)(r + (uint32_t)h * H) + (uint64_t)j * E] = vout[h][j];
+    }
 }
 
 // Fused fold kernel, short-launch form: the chains of 64 ring lanes SPLIT OVER THE FOUR WAVES of a workgroup (one per SIMD).
@@ -606,7 +625,7 @@ __global__ __launch_bounds__(256) void k_fold_split(BhwWinCfg win, BhwFoldPlan p
 
 } // namespace
 
-int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const BhwFoldRun *runs, uint32_t n_runs, int32_t *d_out)
+int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const BhwFoldRun *runs, uint32_t n_runs, int32_t *d_out, uint32_t frames)
 {
     if (!n_runs) return 0;
     if (n_runs > (uint32_t)kFoldRunsMax || !bhwk_fold_direct_applicable(c)) return (int)hipErrorInvalidValue;
@@ -624,6 +643,7 @@ int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg 
     plan.phi_width = c.phi_width;
     plan.dat_width = c.dat_width;
     plan.ones_neg = c.ones_neg;
+    plan.frames = frames ? frames : 1u;
     plan.fast_mul = c.dat_width >= 3 ? 1u : 0u;                          // either cosine-sum rule (the VHDL one keeps its two-word sums)
     for (uint32_t k = 1; k < w.n_terms && plan.fast_mul; ++k) {
         const int64_t lim = (int64_t)1 << (c.dat_width - 3);
@@ -650,7 +670,17 @@ int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg 
     plan.run0_end = plan.r_end[0];
     if (!wg) return 0;
     const int mode = (w.combine != BHW_COMBINE_HLS) ? 2 : (c.ones_neg ? 1 : 0);
-    const dim3 grid(wg), blk(block);
+    // batched identical frames: the frames are divided over grid.y -- enough rows that the launch has ~4 waves per SIMD to keep
+    // the store stream going (each row computes the period again: microseconds of latency, no traffic)
+    uint32_t gy = 1u;
+    if (plan.frames > 1u) {
+        if (split || w.apply_x != nullptr) return (int)hipErrorInvalidValue;    // (the caller sends these through one period + replicate)
+        const uint32_t waves_x = wg * (block >> 6);
+        gy = (4096u + waves_x - 1u) / (waves_x ? waves_x : 1u);
+        if (gy > plan.frames) gy = plan.frames;
+        if (gy < 1u) gy = 1u;
+    }
+    const dim3 grid(wg, gy), blk(block);
     plan.k24 = bhwp_fold_k24(c);
     dim3 grid_s(0), blk_s(256);
     if (split) {

@@ -104,7 +104,8 @@ int bhwk_runlength_window(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWi
 // full-window buffer d_out.  At most 32 runs.
 struct BhwFoldRun { uint32_t r0, r_end; };
 bool bhwk_fold_direct_applicable(const BhwCordicCfg &c);
-int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const BhwFoldRun *runs, uint32_t n_runs, int32_t *d_out);
+// frames > 1: `frames` identical periods back to back from d_out (whole ring, not the split form, no fused apply)
+int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const BhwFoldRun *runs, uint32_t n_runs, int32_t *d_out, uint32_t frames = 1);
 // ring lanes of interleaved-ownership part `part` of `n_parts` as runs (returns the count, <= 32); tile0 / tile_count: the same
 // part as a range of the tile plan's tiles when the tile kernel applies (tile_count 0 otherwise)
 int bhwk_part_runs(const BhwCordicCfg &c, const BhwWinCfg &w, uint32_t part, uint32_t n_parts, BhwFoldRun *runs, uint32_t *tile0, uint32_t *tile_count);

@@ -531,6 +531,26 @@ def test_batched_frames(torch, golden):
     assert np.array_equal(tiny, np.tile(O.generate(O.oparams(7, 4, 16), 0, 16), (3, 1)))
 
 
+@pytest.mark.parametrize("cfg", [
+    # (win, pw, w, model, combine, frames): the one-launch form (periods up to 2^19 the fused kernel takes: every frame written by
+    # the kernel that computes the period) with frame counts that do and do not divide over its workgroup rows ...
+    (4, 16, 24, B.MODEL_HLS, B.COMBINE_HLS, 37), (4, 14, 24, B.MODEL_CPP, B.COMBINE_VHDL, 513), (7, 12, 16, B.MODEL_VHDL, B.COMBINE_VHDL, 1000),
+    (5, 18, 28, B.MODEL_HLS, B.COMBINE_HLS, 9), (3, 19, 20, B.MODEL_CPP, B.COMBINE_HLS, 5), (2, 10, 12, B.MODEL_HLS, B.COMBINE_VHDL, 2),
+    # ... and periods that keep one period + replicate: 2^20, the chains-split form (BH-7 2^16 at 32 bits), a 34-bit-plus state
+    (4, 20, 24, B.MODEL_HLS, B.COMBINE_HLS, 3), (7, 16, 32, B.MODEL_HLS, B.COMBINE_HLS, 11), (7, 12, 32, B.MODEL_VHDL, B.COMBINE_HLS, 6)])
+def test_batched_frames_both_forms_match_the_oracle(torch, cfg):
+    """bhw_generate_batched_device: `frames` identical periods (the stream is periodic, src/bh_win_7term.vhd:92-97), bit-exact in
+    every frame whichever way they are produced."""
+    import blackman_harris_win_amd as bhw
+    win, pw, w, model, combine, frames = cfg
+    p = B.make_params(win, pw, w, model=model, combine=combine, precision=3 if (model == B.MODEL_VHDL and w == 32) else 1)
+    out = bhw.generate_batched(p, frames)
+    assert out.shape == (frames, 1 << pw)
+    want = O.generate_mt(O.from_bhw(p), 0, 1 << pw)
+    assert np.array_equal(out[0].cpu().numpy(), want) and np.array_equal(out[frames - 1].cpu().numpy(), want)
+    assert bool((out == out[0:1]).all())
+
+
 # ---- BASELINE full sizes: checksums + size-independent properties -----------------------------------
 def test_c2_full(torch, golden):
     p = B.make_params(4, 20, 24)

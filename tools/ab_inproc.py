@@ -82,7 +82,15 @@ def main():
         L.bhw_apply_device.argtypes = [ctypes.POINTER(binding.BhwParams), ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
 
+    batched = int(os.environ.get("AB_BATCHED", "0"))      # AB_BATCHED=F: F identical frames (bhw_generate_batched_device) into a buffer of F * 2^PW
+    if batched:
+        out = torch.empty(n * batched, dtype=torch.int32, device="cuda")
+        for L in libs:
+            L.bhw_generate_batched_device.argtypes = [ctypes.POINTER(binding.BhwParams), ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+
     def call(L):
+        if batched:
+            return L.bhw_generate_batched_device(ctypes.byref(p), 0, ctypes.c_void_p(st), batched, ctypes.c_void_p(out.data_ptr()))
         if apply:
             return L.bhw_apply_device(ctypes.byref(p), 0, ctypes.c_void_p(st), 0, n, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()), 31)
         if parts:
