@@ -583,6 +583,7 @@ __global__ __launch_bounds__(tile_wg_of(NB)) __attribute__((amdgpu_waves_per_eu(
         init_acc(std::integral_constant<int, -1>{}); run_harmonics(std::integral_constant<int, -1>{});
         BHW_CSTAMP_MIN(2);                                           // first wave reaches its stores
         BHW_CSTAMP_MAX(3);                                           // last wave reaches its stores
+        // (s_setprio 3 for the store phase, or for the set-up and first loads: +-0.3 us, nothing)
         store_runs(std::integral_constant<int, -1>{});
     }
     BHW_CSTAMP_MAX(4);                                               // last wave has issued its stores
