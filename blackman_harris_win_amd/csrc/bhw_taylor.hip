@@ -315,9 +315,9 @@ int bhwk_taylor_window_fold(const BhwLaunch &l, const BhwTaylorCfg &t, const Bhw
     bool narrow = t.dat_width <= 16;
     for (uint32_t k = 0; k < w.n_terms; ++k) narrow = narrow && w.aa[k] < (1 << 15) && w.aa[k] >= -(1 << 15);
     unsigned blocks = grid_for(E / 4);
-    // grid-stride above 8 192 workgroups (Hamming 2^26 / 16-bit per call: 0.0564 / 0.0514 / 0.0465 / 0.0450 / 0.0458 ms at caps of
-    // 1 024 / 2 048 / 4 096 / 8 192 / 16 384)
-    if (blocks > 8192u) blocks = 8192u;
+    // grid-stride above 4 096 workgroups.  (A cap of 8 192 reads 3 % better per isolated call -- 0.0465 -> 0.0450 ms -- and 3 % worse
+    // back to back, which is what the kernel's own duration shows: 42.0 -> 43.3 us under rocprofv3.  4 096 stays.)
+    if (blocks > 4096u) blocks = 4096u;
     const dim3 grid(blocks);
     hipStream_t st = (hipStream_t)l.stream;
 #define BHW_TAYLOR_FOLD(ARITH, COMBINE, NT) BHW_LAUNCH((k_taylor_window_fold<ARITH, COMBINE, NT, true>), grid, dim3(kBlock), 0, st, t, w, d_out)
