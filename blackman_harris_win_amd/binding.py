@@ -9,7 +9,7 @@ COMBINE_HLS, COMBINE_VHDL = 0, 1
 SIN_CORDIC, SIN_TAYLOR, SIN_TAYLOR_ALL = 0, 1, 2
 WIN_HAMMING, WIN_HANN, WIN_BH3, WIN_BH4, WIN_BH5, WIN_BH7 = 1, 2, 3, 4, 5, 7
 ALGO_AUTO, ALGO_DIRECT, ALGO_TABLE, ALGO_FUSED = 0, 1, 2, 3
-TABLE_BEST, TABLE_PLAIN, TABLE_DELTA16, TABLE_RESIDUAL, TABLE_NIBBLE = 0, 1, 2, 3, 4
+TABLE_BEST, TABLE_PLAIN, TABLE_DELTA16, TABLE_RESIDUAL, TABLE_NIBBLE, TABLE_NIBBLE_ESC = 0, 1, 2, 3, 4, 5
 ABI_VERSION = 4
 
 # every symbol include/bhw.h declares (tests check the library exports all of them)

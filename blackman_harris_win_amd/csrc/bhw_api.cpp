@@ -195,6 +195,8 @@ int build_table(const bhw_params *p, const BhwLaunch &l, BhwCordicCfg &c, bool t
         const BhwTableLayout lay = bhwp_table_layout(E, dlog);
         c.tab_dlog = dlog;
         c.tab_coarse = dlog ? (const void *)((const char *)ws + lay.coarse_off) : nullptr;
+        c.tab_esc = lay.esc_off ? (const void *)((const char *)ws + lay.esc_off) : nullptr;
+        c.esc_wg_log = lay.esc_wg_log;
         c.tab_check = nullptr;
         if (verdict == kFmtUnknown) {
             c.tab_check = (uint32_t *)((char *)ws + lay.check_off);
@@ -485,7 +487,10 @@ static void dbg_verified_format(const bhw_params *p, BhwCordicCfg &c, bool tiled
     c.tab_dlog = 0;
     for (int i = 0; i < n; ++i)
         if (cand[i] && bhwp_fmt_verdict(p, cand[i]) == kFmtOk) { c.tab_dlog = cand[i]; break; }
-    c.tab_coarse = c.tab_dlog ? (const void *)((const char *)ws + bhwp_table_layout(bhwp_table_entries(c), c.tab_dlog).coarse_off) : nullptr;
+    const BhwTableLayout lay = bhwp_table_layout(bhwp_table_entries(c), c.tab_dlog);
+    c.tab_coarse = c.tab_dlog ? (const void *)((const char *)ws + lay.coarse_off) : nullptr;
+    c.tab_esc = lay.esc_off ? (const void *)((const char *)ws + lay.esc_off) : nullptr;
+    c.esc_wg_log = lay.esc_wg_log;
     c.tab_check = nullptr;
 }
 
@@ -524,7 +529,7 @@ int bhw_dbg_table_combine(const bhw_params *p, int device, void *stream, const v
 // the format would be chosen for this configuration, and returns the check word.  `ws`: bhw_workspace_bytes(TABLE) bytes.
 int bhw_dbg_check_table_format(const bhw_params *p, int device, void *stream, uint32_t dlog, void *ws, uint32_t *flag_out)
 {
-    if (bhwp_validate(p) || !ws || !flag_out || dlog < 6 || (dlog > 9 && (dlog < 16u + 7u || dlog > 16u + 9u))) return BHW_ERR_BADARG;
+    if (bhwp_validate(p) || !ws || !flag_out || dlog < 6 || (dlog > 9 && (dlog < 16u + 7u || dlog > 16u + 9u) && (dlog < 48u + 7u || dlog > 48u + 9u))) return BHW_ERR_BADARG;
     BhwCordicCfg c;
     bhwp_resolve_cordic(p, c);
     if (c.z_shr != 0 || c.n_iter < 21 || c.dat_width + c.out_shr > 34 || bhwp_table_entries(c) < (1ull << 20)) return BHW_ERR_UNSUPPORTED;   // packed tables exist for tiled windows (PW >= 22) only
@@ -533,6 +538,8 @@ int bhw_dbg_check_table_format(const bhw_params *p, int device, void *stream, ui
     c.tab_split = 1u;
     c.tab_dlog = dlog;
     c.tab_coarse = (const char *)ws + lay.coarse_off;
+    c.tab_esc = lay.esc_off ? (const void *)((const char *)ws + lay.esc_off) : nullptr;
+    c.esc_wg_log = lay.esc_wg_log;
     c.tab_check = (uint32_t *)((char *)ws + lay.check_off);
     hipError_t he = hipMemsetAsync(c.tab_check, 0, 8, (hipStream_t)stream);
     if (he != hipSuccess) return BHW_ERR_HIP;

@@ -412,7 +412,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
         g_build_stamps[blockIdx.x * 16u + 7u] = xcc;
     }
 #endif
-    static_assert(FMT == 2 || FMT == 3, "residual / nibble entries");
+    static_assert(FMT == 2 || FMT == 3 || FMT == 5, "residual / nibble entries");
     static_assert(NITER >= 21 && NITER <= 32, "narrow state: 32-bit words");
     static_assert(THREADS == 256 || THREADS == 1024, "workgroup shapes");
     constexpr uint32_t gpw = mirror_gpw(THREADS);               // own groups per workgroup
@@ -429,9 +429,15 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
     constexpr uint32_t kWorkMax = 8 * gpw;           // images to run as chains of their own (expected ~0.6 per group)
     __shared__ uint32_t work_n;
     __shared__ uint32_t work_u[kWorkMax];
+    __shared__ uint32_t esc_n;                       // nibble + escapes: entries this workgroup has listed
+    __shared__ int4 esc_list[FMT == 5 ? kEscFill : 1];   // ... in arrival order; hashed into esc_tab (esc_lookup) and written out at the end
+    __shared__ int4 esc_tab[FMT == 5 ? kEscSlots : 1];
     // (all kernel arguments requested in one batch of scalar loads up front: measured, no gain -- 0.0966 / 0.0977 ms; the serial start is
     // bound by the dependent 64-bit rotations of the prefix and head chains, profiles/r04_build_timeline_final.txt)
     if (threadIdx.x < 32) lut_s[threadIdx.x] = plan.lut[threadIdx.x];
+    if constexpr (FMT == 5) {
+        if (threadIdx.x >= 64u && threadIdx.x < 64u + kEscSlots) esc_tab[threadIdx.x - 64u] = make_int4(-1, 0, 0, 0);   // (first used behind the barriers below)
+    }
 #ifdef BHW_BUILD_STAMPS
     if (g_build_stamps && threadIdx.x == 0u) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g_build_stamps[blockIdx.x * 16u + 8u] = (unsigned long long)wall_clock64() | (plan.entries & 0u); }   // kernel arguments have arrived
 #endif
@@ -446,6 +452,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const uint32_t m_last = (E >> 1) - 1u;    // u in [1, m_last] also produce the image E - u
     if (threadIdx.x == 0) {
         work_n = 0u;
+        esc_n = 0u;
         if (u_hi == (E >> 1)) {                  // the middle entry E/2 (its own image): one more deferred chain
             work_u[0] = E >> 1;
             work_n = 1u;
@@ -578,7 +585,16 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
     auto store_entry = [&](uint32_t idx, int32_t c, int32_t sn, const int4 rec, uint32_t pos) {
         const int2 p = tab_predict(rec, pos, d);
         const int32_t dc = c - p.x, ds = sn - p.y;
-        if constexpr (FMT == 3) {
+        if constexpr (FMT == 5) {
+            // the deviation that does not fit (or collides with the marker) goes to this workgroup's list, the marker into the table
+            uint32_t v = ((uint32_t)dc & 0xFu) | ((uint32_t)ds << 4);
+            if (__builtin_expect(!(fits_bits(dc, 4) && fits_bits(ds, 4)) || dc == -8, 0)) {
+                const uint32_t slot = atomicAdd(&esc_n, 1u);
+                if (slot < kEscFill) esc_list[slot] = make_int4((int32_t)idx, c, sn, 0);    // (beyond: the format is refused below)
+                v = kEscMarker;
+            }
+            table_store<1>(table, idx, v);
+        } else if constexpr (FMT == 3) {
             if (plan.check_flag && !(fits_bits(dc, 4) && fits_bits(ds, 4))) atomicOr(plan.check_flag, 1u);
             table_store<1>(table, idx, ((uint32_t)dc & 0xFu) | ((uint32_t)ds << 4));              // bits 8.. are not stored
         } else {
@@ -745,6 +761,23 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
         for (int r = 1; r < n_iter; ++r) rot_step(xf, yf, zf, r, plan.lut[r]);     // (restarting from the group's parked state, per-lane start rotation: +0.3 us)
         store_entry(tab_index(um, plan.log2_entries, plan.tab_split), (int32_t)(xf >> plan.out_shr), (int32_t)(yf >> plan.out_shr), record_of(1, um >> d), um & fmask);
     }
+    if constexpr (FMT == 5) {                                        // the list's length; a list that overflowed fails the format
+        __syncthreads();
+        const uint32_t n_esc = esc_n < kEscFill ? esc_n : kEscFill;
+        if (threadIdx.x < n_esc) {                                   // one lane per listed entry: its slot by open addressing
+            const int4 it = esc_list[threadIdx.x];
+            uint32_t h = esc_slot((uint32_t)it.x);
+#pragma unroll 1
+            for (uint32_t i = 0; i < kEscSlots; ++i) {
+                const uint32_t was = atomicCAS(reinterpret_cast<uint32_t *>(&esc_tab[h].x), ~0u, (uint32_t)it.x);
+                if (was == ~0u || was == (uint32_t)it.x) { esc_tab[h].y = it.y; esc_tab[h].z = it.z; break; }
+                h = (h + 1u) & (kEscSlots - 1u);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < kEscSlots) reinterpret_cast<int4 *>(plan.tab_esc)[(size_t)blockIdx.x * kEscSlots + threadIdx.x] = esc_tab[threadIdx.x];
+        if (threadIdx.x == 0u && esc_n > kEscFill && plan.check_flag) atomicOr(plan.check_flag, 1u);
+    }
     BHW_STAMP(5);
 }
 
@@ -789,6 +822,7 @@ int bhwk_sincos_sweep(const BhwLaunch &l, const BhwCordicCfg &c, uint64_t theta0
     plan.tab_coarse = d_cos;
     plan.x0 = c.x0;
     plan.check_flag = nullptr;
+    plan.tab_esc = nullptr;
     const unsigned groups = plan.entries >> 6;
     plan.groups_per_wg = groups >= 64u * 1024u ? 64u : groups >= 16u * 1024u ? 16u : 4u;
     plan.pad = (uint32_t)(theta0 & ((1ull << c.phi_width) - 1ull));
@@ -848,6 +882,7 @@ int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c_in, int32_t *d_ta
         plan.tab_coarse = c.tab_coarse;
         plan.x0 = c.x0;
         plan.check_flag = c.tab_check;
+        plan.tab_esc = const_cast<void *>(c.tab_esc);
         const unsigned groups = entries >> 6;
         plan.groups_per_wg = groups >= 64u * 1024u ? 64u : groups >= 16u * 1024u ? 16u : 4u;
         plan.pad = 0;
@@ -866,7 +901,7 @@ int bhwk_table_build(const BhwLaunch &l, const BhwCordicCfg &c_in, int32_t *d_ta
             switch (c.n_iter) {
 #define BHW_CASE_MT(N, F) do { if (threads == 1024u) BHW_LAUNCH((k_table_build_mirror<N, F, 1024>), mgrid, mblock, 0, st, plan, (void *)d_table); \
                                else                  BHW_LAUNCH((k_table_build_mirror<N, F, 256>), mgrid, mblock, 0, st, plan, (void *)d_table); } while (0)
-#define BHW_CASE_M(N) case N: if (fmt == 2) BHW_CASE_MT(N, 2); else BHW_CASE_MT(N, 3); break;
+#define BHW_CASE_M(N) case N: if (fmt == 2) BHW_CASE_MT(N, 2); else if (fmt == 3) BHW_CASE_MT(N, 3); else BHW_CASE_MT(N, 5); break;
                 BHW_CASE_M(21) BHW_CASE_M(22) BHW_CASE_M(23) BHW_CASE_M(24) BHW_CASE_M(25) BHW_CASE_M(26) BHW_CASE_M(27) BHW_CASE_M(28)
                 BHW_CASE_M(29) BHW_CASE_M(30) BHW_CASE_M(31) BHW_CASE_M(32)
 #undef BHW_CASE_M

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(tile_wg_of(NB)) __attribute__((amdgpu_waves_per_eu(
     }
     const uint32_t part = kWgPerTile > 1 ? part_of_block / kWgPerPart : __builtin_amdgcn_readfirstlane(threadIdx.x / kLanes);   // wave-uniform: kLanes is a multiple of 64
     const uint32_t lane_in_part = kWgPerTile > 1 ? (part_of_block % kWgPerPart) * kWgThreads + threadIdx.x : threadIdx.x % kLanes;
-    constexpr bool kLdsRec = (FMT == 2 || FMT == 3) && NB >= 15 && kLanes == kTileLanes;
+    constexpr bool kLdsRec = fmt_is_resid(FMT) && NB >= 15 && kLanes == kTileLanes;
     uint32_t rec_meta = 0;                                           // slot -> (K, g, j) of the record staging below, fetched first
     if constexpr (kLdsRec) rec_meta = kRecMeta.v[threadIdx.x & 63u];
     uint32_t rr[NR], starts[NR];
@@ -305,10 +305,10 @@ __global__ __launch_bounds__(tile_wg_of(NB)) __attribute__((amdgpu_waves_per_eu(
             _Pragma("unroll") for (int b = B0; b < B1; ++b) {                                            \
                 _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                         \
                     if (MASKED && NG == 2 && !(g ? want1 : want0)) continue;                             \
-                    if constexpr (FMT == 2 || FMT == 3) {                                               \
+                    if constexpr (fmt_is_resid(FMT)) {                                             \
                         const uint32_t rg = rr[b] + (uint32_t)g * H;                                     \
                         const uint32_t boff = resid_offset<FMT, K>(rg, (uint32_t)K * rg, cls[b], lq, emask); \
-                        land[gather_order(K, b, g)] = FMT == 3 ? ld_nibble<K>(table, boff) : (uint32_t)ld_off<uint16_t>(table, boff); \
+                        land[gather_order(K, b, g)] = fmt_is_nibble(FMT) ? ld_nibble<K>(table, boff) : (uint32_t)ld_off<uint16_t>(table, boff); \
                     }                                                                                    \
                 }                                                                                        \
             }                                                                                            \
@@ -398,26 +398,44 @@ __global__ __launch_bounds__(tile_wg_of(NB)) __attribute__((amdgpu_waves_per_eu(
         constexpr int NG = (K & 1) ? 2 : 1;                                                              \
         constexpr int KC = (K % 4 == 0) ? 4 : (K % 2 == 0) ? 2 : 0;   /* split layout only exists at z_shr == 0 */ \
         int2 cs[NR][NG];                                                                                 \
+        int32_t esc_min = 0;                                                                             \
         _Pragma("unroll") for (int b = B0; b < B1; ++b) {                                                 \
             _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                             \
                 if (MASKED && NG == 2 && !(g ? want1 : want0)) continue;                                 \
                 const uint32_t rg = rr[b] + (uint32_t)g * H;                                             \
                 const uint32_t theta = (uint32_t)K * rg;                                                 \
-                if constexpr (NB > 1 && (FMT == 2 || FMT == 3)) {                                        \
+                if constexpr (NB > 1 && fmt_is_resid(FMT)) {                                             \
                     uint32_t bias = rbias[rec_set_index(K, g)][b];                                       \
                     if constexpr (LDS) asm("" : "+s"(bias));    /* one scalar: the record address is shift, shift-add */ \
                     uint32_t e;                                                                          \
                     if constexpr (kPrefetch && LDS) e = land[gather_order(K, b, g)];                     \
                     else {                                                                               \
                         const uint32_t boff = resid_offset<FMT, K>(rg, theta, cls[b], lq, emask_v);     \
-                        e = FMT == 3 ? ld_nibble<K>(table, boff) : (uint32_t)ld_off<uint16_t>(table, boff); \
+                        e = fmt_is_nibble(FMT) ? ld_nibble<K>(table, boff) : (uint32_t)ld_off<uint16_t>(table, boff); \
                     }                                                                                    \
                     cs[b][g] = resid_value<FMT, LDS>(cfg, theta, emask_v, rk, lrec, bias, e);            \
+                    if constexpr (FMT == 5) {                                                            \
+                        const int32_t dcv = (int32_t)(e << 28) >> 28;                                    \
+                        esc_min = dcv < esc_min ? dcv : esc_min;                                         \
+                    }                                                                                    \
                 } else if constexpr (NB > 1 && (K & 1)) cs[b][g] = tab_load_class<FMT>(cfg, table, theta & emask_v, cls[b]); \
                 else if constexpr (NB > 1) {                                                             \
                     const uint32_t u = theta & emask_v;                                                  \
                     cs[b][g] = tab_fetch<FMT>(cfg, table, u, tab_index<KC, 1>(u, lq, 1u));              \
                 } else cs[b][g] = tab_load<KC, FMT, -1>(cfg, table, (theta & emask) >> cfg.z_shr, lq - cfg.z_shr); \
+            }                                                                                            \
+        }                                                                                                \
+        if constexpr (NB > 1 && FMT == 5) {                                                              \
+            /* nibble + escapes: one test per harmonic (the minimum of its low fields is the marker); the listed entries are a few   \
+               per million, so the branch is almost never taken and the loads of the next harmonic are not held up by six of them */ \
+            if (__builtin_expect(esc_min == -(int32_t)kEscMarker, 0)) {                                  \
+                _Pragma("unroll") for (int b = B0; b < B1; ++b) {                                         \
+                    _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                     \
+                        if (MASKED && NG == 2 && !(g ? want1 : want0)) continue;                         \
+                        const uint32_t ue = ((uint32_t)K * (rr[b] + (uint32_t)g * H)) & emask_v;       /* (natural layout: the word again) */ \
+                        esc_fix_wave(cfg.tab_esc, cfg.esc_wg_log, lq, ue, (ld_off<uint8_t>(table, ue) & 0xFu) == kEscMarker, cs[b][g]); \
+                    }                                                                                    \
+                }                                                                                        \
             }                                                                                            \
         }                                                                                                \
         _Pragma("unroll") for (int b = B0; b < B1; ++b) {                                                 \
@@ -789,7 +807,8 @@ int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c_in, 
         if (c.tab_dlog == 0)             BHW_LAUNCH((k_table_combine_tile<NB, M, 0, F, K>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
         else if (c.tab_dlog == kPackLog) BHW_LAUNCH((k_table_combine_tile<NB, M, 1, F, K>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
         else if (c.tab_dlog < kNibbleFlag) BHW_LAUNCH((k_table_combine_tile<NB, M, 2, F, K>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
-        else                             BHW_LAUNCH((k_table_combine_tile<NB, M, 3, F, K>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
+        else if (c.tab_dlog < kEscFlag)  BHW_LAUNCH((k_table_combine_tile<NB, M, 3, F, K>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
+        else                             BHW_LAUNCH((k_table_combine_tile<NB, M, 5, F, K>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
     } while (0)
 #define BHW_LAUNCH_TILE_MF(NB, M, F)                                                                                     \
     do {                                                                                                                 \

@@ -104,6 +104,13 @@ __device__ __forceinline__ uint32_t tab_index(uint32_t u, uint32_t log2_entries,
 //          of the 32-bit HLS model stay within -5 .. 6 over the whole 2^24-entry table of a 2^26-point window (measured with the
 //          oracle); like the other packed formats it is used only after the build kernel has checked every entry of the
 //          configuration (a model whose noise is wider -- the cpp model reaches 10 -- falls back to the byte fields).
+//   55..57 "nibble + escapes" (48 + d): the nibble format with the low field -8 reserved as a marker: that entry's exact pair is in
+//          the hash table (kEscSlots slots, esc_lookup) of the build workgroup that stored it, at cfg.tab_esc.  For the models whose
+//          noise is a little wider than the fields -- cpp, VHDL at 32 bits: about 1 000 / 1 500 of the 2^24 entries of a 2^26-point
+//          window, at most 66 / 75 in one workgroup (tests/test_oracle.py::test_nibble_escape_capacity) -- so that they too read one
+//          byte per entry.  The tile kernel tests the minimum of a harmonic's low fields (one v_min per gather, one branch per
+//          harmonic) and resolves the rare marked lane on the scalar unit (esc_fix_wave); a workgroup whose table would fill
+//          beyond kEscFill sets the check word and the configuration falls back to the byte fields.
 // The combine pass is bound by table + output traffic as much as by arithmetic, and these cut the table's share to 1/2 .. 1/8.
 // (kPackLog, kNibbleFlag, fmt_cell_log(), fmt_of(), table_layout(): bhw_plan.h, shared with the HIP-free planner)
 
@@ -137,6 +144,58 @@ struct ResidK {
     uint32_t fmask;   // 2^d - 1
 };
 
+// Nibble + escapes: the entry whose low field holds the marker -8 is listed exactly.  Entry u of [0, E) was stored by the build
+// workgroup that owns its source min(u, E - u) (the middle entry E/2 by the last one); that workgroup's list is a hash table of
+// kEscSlots slots { u or -1, c, s, - }, open addressing from esc_slot(u).  A few entries per million (the cpp model at 2^26 /
+// 32 bits: 1 005 of 2^24), at most kEscFill per workgroup: one or two probes, and the branch that leads here is cold.
+constexpr uint32_t kEscMarker = 8u;
+__device__ __forceinline__ uint32_t esc_slot(uint32_t u) { return (u * 0x9E3779B1u) >> 25; }
+static_assert(kEscSlots == 128, "esc_slot: seven bits");
+__device__ __forceinline__ int2 esc_lookup(const void *__restrict__ esc, uint32_t esc_wg_log, uint32_t log2_entries, uint32_t u)
+{
+    const uint32_t E = 1u << log2_entries, half = E >> 1;
+    uint32_t own = u <= half ? u : E - u;
+    if (own > half - 1u) own = half - 1u;
+    const int4 *tab = reinterpret_cast<const int4 *>(esc) + (size_t)(own >> esc_wg_log) * kEscSlots;
+    uint32_t h = esc_slot(u);
+    int2 r = make_int2(0, 0);
+    for (uint32_t i = 0; i < kEscSlots; ++i) {                      // (bounded: a marker without its entry cannot happen)
+        const int4 e = tab[h];
+        if ((uint32_t)e.x == u) { r = make_int2(e.y, e.z); break; }
+        h = (h + 1u) & (kEscSlots - 1u);
+    }
+    return r;
+}
+
+// The same for the lanes of a wave that hold a marked entry (`marked`, u = the entry), on the scalar unit: one lane at a time, its
+// index read into an SGPR, the probes as scalar loads, the pair written back into that lane.  No vector register beyond the two
+// of the caller -- the tile kernel has none to spare (62 of 64 at eight waves per SIMD) -- and the path is cold.
+typedef int bhw_v4i __attribute__((ext_vector_type(4)));
+typedef const bhw_v4i __attribute__((address_space(4))) *BhwEscConstPtr;
+__device__ __forceinline__ void esc_fix_wave(const void *__restrict__ esc, uint32_t esc_wg_log, uint32_t log2_entries, uint32_t u, bool marked, int2 &cs)
+{
+    const uint32_t E = 1u << log2_entries, half = E >> 1;
+    uint64_t m = __ballot(marked);
+    while (m) {
+        const uint32_t l = (uint32_t)__builtin_ctzll(m);
+        m &= m - 1ull;
+        const uint32_t us = __builtin_amdgcn_readlane(u, l);
+        uint32_t own = us <= half ? us : E - us;
+        if (own > half - 1u) own = half - 1u;
+        BhwEscConstPtr tab = (BhwEscConstPtr)(uintptr_t)(reinterpret_cast<const int4 *>(esc) + (size_t)(own >> esc_wg_log) * kEscSlots);
+        uint32_t h = esc_slot(us);
+        int32_t rc = 0, rs = 0;
+#pragma unroll 1
+        for (uint32_t i = 0; i < kEscSlots; ++i) {
+            const bhw_v4i e = tab[h];
+            if ((uint32_t)e.x == us) { rc = e.y; rs = e.z; break; }
+            h = (h + 1u) & (kEscSlots - 1u);
+        }
+        // (one SGPR per vector instruction on gfx9: the lane select goes through M0)
+        asm volatile("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0" : "+v"(cs.x), "+v"(cs.y) : "s"(rc), "s"(rs), "s"(l) : "m0");
+    }
+}
+
 template <int FMT = -1>
 __device__ __forceinline__ int2 tab_fetch(const BhwCordicCfg &cfg, const void *__restrict__ table, uint32_t u, uint32_t idx)
 {
@@ -148,8 +207,11 @@ __device__ __forceinline__ int2 tab_fetch(const BhwCordicCfg &cfg, const void *_
     }
     const uint32_t d = fmt_cell_log(cfg.tab_dlog);
     const int2 p = tab_predict(ld_off<int4>(cfg.tab_coarse, (u >> d) << 4), u & ((1u << d) - 1u), d);
-    if (FMT == 3 || (FMT < 0 && cfg.tab_dlog >= kNibbleFlag)) {
+    if (FMT == 3 || FMT == 5 || (FMT < 0 && cfg.tab_dlog >= kNibbleFlag)) {
         const uint32_t e = ld_off<uint8_t>(table, idx);
+        if (FMT == 5 || (FMT < 0 && cfg.tab_dlog >= kEscFlag)) {
+            if ((e & 0xFu) == kEscMarker) return esc_lookup(cfg.tab_esc, cfg.esc_wg_log, cfg.phi_width - 2u, u);
+        }
         return make_int2(p.x + ((int32_t)(e << 28) >> 28), p.y + ((int32_t)(e << 24) >> 28));
     }
     const uint32_t e = ld_off<uint16_t>(table, idx << 1);
@@ -164,14 +226,15 @@ template <int FMT, bool LDS>
 __device__ __forceinline__ int2 resid_value(const BhwCordicCfg &cfg, uint32_t theta, uint32_t emask, const ResidK &rk, const char *lrec, uint32_t bias,
                                             uint32_t e)
 {
-    static_assert(FMT == 2 || FMT == 3, "residual / nibble entries");
+    static_assert(FMT == 2 || FMT == 3 || FMT == 5, "residual / nibble entries");
     int4 rec;
     if constexpr (LDS) rec = *reinterpret_cast<const int4 *>(lrec + (((theta >> rk.d) << 4) + bias));
     else rec = ld_off<int4>(cfg.tab_coarse, ((theta & emask) >> rk.d) << 4);
     // (the predictor as two shifts + two v_mul_hi_i32 on doubled slopes -- one instruction fewer per gather -- measured slower:
     // 0.1358 -> 0.1367 ms, profiles/r02_ab_tile_memory_path.txt)
     const int2 p = tab_predict(rec, theta & rk.fmask, rk.d);
-    if constexpr (FMT == 3) return make_int2(p.x + ((int32_t)(e << 28) >> 28), p.y + ((int32_t)(e << 24) >> 28));
+    // (FMT 5: the caller looks for the escape marker, once per harmonic -- BHW_TILE_HARMONIC)
+    if constexpr (FMT == 3 || FMT == 5) return make_int2(p.x + ((int32_t)(e << 28) >> 28), p.y + ((int32_t)(e << 24) >> 28));
     else return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
 }
 
@@ -196,7 +259,7 @@ __device__ __forceinline__ uint32_t split_class(uint32_t r, uint32_t log2_entrie
 {
     const uint32_t e = 1u << log2_entries;
     const uint32_t s = (r & 1u) ? 1u : 2u;
-    if constexpr (FMT == 2 || FMT == 3) return ((r & 3u) ? e : 0u) | (s - 1u);      // (FMT 3: unused, natural layout)
+    if constexpr (FMT == 2 || FMT == 3 || FMT == 5) return ((r & 3u) ? e : 0u) | (s - 1u);      // (FMT 3, 5: unused, natural layout)
     constexpr uint32_t LB = FMT == 1 ? 2u : 3u;
     const uint32_t base = (r & 1u) ? (e >> 1) : (((r >> 1) & 1u) ? (e >> 2) : 0u);
     return (base << LB) | (LB - s);                                  // left by LB - s (0 .. 2)
@@ -228,8 +291,8 @@ __device__ __forceinline__ int2 tab_load_class(const BhwCordicCfg &cfg, const vo
 template <int FMT, int K>
 __device__ __forceinline__ uint32_t resid_offset(uint32_t rg, uint32_t theta, uint32_t cls, uint32_t lq, uint32_t emask)
 {
-    static_assert(FMT == 2 || FMT == 3, "residual / nibble entries");
-    if constexpr (FMT == 3) {                                       // nibble tables keep the natural layout (table_layout)
+    static_assert(FMT == 2 || FMT == 3 || FMT == 5, "residual / nibble entries");
+    if constexpr (FMT == 3 || FMT == 5) {                           // nibble tables keep the natural layout (table_layout)
         if constexpr (K <= 2) return theta;                        // K (r + g E/2) < E for r < E/2: nothing to wrap
         else return theta & emask;
     }
@@ -335,6 +398,7 @@ struct BhwBuildPlan {
     uint32_t pad;
     int64_t  x0;
     uint32_t *check_flag;     // packed formats: set to 1 when a difference does not fit its field (NULL: configuration already verified)
+    void *tab_esc;            // nibble + escapes: the per-workgroup escape lists (BhwCordicCfg::tab_esc)
 };
 
 // lut[k] < 2^23 for every k >= 9 whenever the fast path is legal (lut[k] <= atan(2^-k) 2^33 / pi), so the

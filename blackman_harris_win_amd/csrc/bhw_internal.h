@@ -26,8 +26,13 @@ struct BhwCordicCfg {
                           // two int16 differences to the first entry of the 64-entry block, block heads as int2 records at
                           // tab_coarse; 7..9 "residual" -- two bytes per entry against a linear predictor, int4 {c, s, dc, ds}
                           // records every 2^tab_dlog entries at tab_coarse
+                          // 23..25 (16 + d) "nibble": the residual format in 4-bit fields; 55..57 (48 + d) "nibble + escapes": the same with a
+                          // reserved marker value for the rare entry whose deviation does not fit, listed exactly at tab_esc
     const void *tab_coarse;
     uint32_t *tab_check;  // build pass, packed formats: device word set to 1 when an entry does not fit its field (NULL: no check)
+    const void *tab_esc;  // nibble + escapes: per build workgroup a hash table of kEscSlots x { entry index or -1, c, s, - }
+    uint32_t esc_wg_log;  // ... log2 of the table entries one build workgroup owns (its own range; the images mirror it)
+    uint32_t pad_esc;
 };
 
 // Cosine-sum stage.

@@ -244,7 +244,7 @@ int bhwp_check_exec(const bhw_exec *ex)
     if (!ex) return BHW_OK;
     if (ex->struct_size != sizeof(bhw_exec) && ex->struct_size != 32u)       // 32 = the ABI-1 layout (no table_format)
         return bhwp_fail(BHW_ERR_BADARG, "bhw_exec.struct_size %u", ex->struct_size);
-    if (ex->struct_size >= sizeof(bhw_exec) && (ex->table_format > BHW_TABLE_NIBBLE || ex->reserved != 0))
+    if (ex->struct_size >= sizeof(bhw_exec) && (ex->table_format > BHW_TABLE_NIBBLE_ESC || ex->reserved != 0))
         return bhwp_fail(BHW_ERR_BADARG, "bhw_exec.table_format %u / reserved %u", ex->table_format, ex->reserved);
     return BHW_OK;
 }
@@ -278,7 +278,7 @@ uint32_t bhwk_resid_dlog(const BhwCordicCfg &c)
 bool bhwk_build_mirror_applies(const BhwCordicCfg &c, uint32_t entries)
 {
     const int fmt = fmt_of(c.tab_dlog);
-    return (fmt == 2 || fmt == 3) && (c.tab_split || fmt == 3) && c.z_shr == 0 && entries >= (1u << 20) && c.n_iter >= 21 &&
+    return (fmt == 2 || fmt == 3 || fmt == 5) && (c.tab_split || fmt != 2) && c.z_shr == 0 && entries >= (1u << 20) && c.n_iter >= 21 &&
            c.dat_width + c.out_shr <= 34 && 2ull * (uint64_t)(uint32_t)c.lut[0] == ((uint64_t)entries << c.z_shl);
 }
 
@@ -296,13 +296,25 @@ BhwTableLayout bhwp_table_layout(uint64_t E, uint32_t tab_dlog)
     const uint64_t coarse_bytes = fmt == 0 ? 0ull : fmt == 1 ? (E >> kPackLog) * 8ull : (E >> fmt_cell_log(tab_dlog)) * 16ull;
     BhwTableLayout l;
     l.coarse_off = align256(E * entry_bytes);
+    l.esc_off = 0;
+    l.esc_wg_log = 0;
     l.check_off = l.coarse_off + align256(coarse_bytes);
+    if (fmt == 5) {
+        // one list per workgroup of the mirror build kernel: it owns 64 x (threads / 4) entries of [0, E/2) and their images
+        const uint32_t gpw = bhwk_build_mirror_threads((uint32_t)E) / 4u;
+        uint32_t lg = 6;
+        while ((1u << (lg - 6)) < gpw) ++lg;
+        l.esc_wg_log = lg;
+        const uint64_t n_wg = ((E >> 1) + (1ull << lg) - 1ull) >> lg;
+        l.esc_off = l.check_off;
+        l.check_off = l.esc_off + align256(n_wg * kEscSlots * 16ull);
+    }
     l.bytes = fmt == 0 ? E * 8ull : l.check_off + 256ull;          // plain tables carry neither records nor a check word
     return l;
 }
 
-// Table formats a tiled whole-period call may use, narrowest first (tab_dlog values: 16 + d nibble, d = 7..9 residual, 6 delta16,
-// 0 plain).  The packed build variants exist from 21 rotations on (always true at PW >= 22).  Residual / nibble tables are built
+// Table formats a tiled whole-period call may use, narrowest first (tab_dlog values: 16 + d nibble, 48 + d nibble + escapes,
+// d = 7..9 residual, 6 delta16, 0 plain).  The packed build variants exist from 21 rotations on (always true at PW >= 22).  Residual / nibble tables are built
 // by the octant-mirror kernel only, so they are proposed only where it applies.
 int bhwp_table_format_candidates(const BhwCordicCfg &c, bool tiled, uint32_t limit, uint32_t out[kMaxFormats])
 {
@@ -316,7 +328,10 @@ int bhwp_table_format_candidates(const BhwCordicCfg &c, bool tiled, uint32_t lim
             if (!bhwk_build_mirror_applies(probe, (uint32_t)bhwp_table_entries(c))) d = 0;
         }
         if (d && (limit == BHW_TABLE_BEST || limit == BHW_TABLE_NIBBLE)) out[n++] = kNibbleFlag + d;
-        if (d && (limit == BHW_TABLE_BEST || limit == BHW_TABLE_NIBBLE || limit == BHW_TABLE_RESIDUAL)) out[n++] = d;
+        // the same one-byte entries with the rare deviation that does not fit listed exactly (models whose CORDIC noise is wider than
+        // the 4-bit fields: cpp, VHDL at 32 bits)
+        if (d && (limit == BHW_TABLE_BEST || limit == BHW_TABLE_NIBBLE || limit == BHW_TABLE_NIBBLE_ESC)) out[n++] = kEscFlag + kNibbleFlag + d;
+        if (d && (limit == BHW_TABLE_BEST || limit == BHW_TABLE_NIBBLE || limit == BHW_TABLE_NIBBLE_ESC || limit == BHW_TABLE_RESIDUAL)) out[n++] = d;
         if (bhwk_packed_ok(c) && limit != BHW_TABLE_PLAIN) out[n++] = kPackLog;
     }
     out[n++] = 0u;
@@ -333,7 +348,8 @@ int bhwp_fmt_verdict(const bhw_params *p, uint32_t dlog)
 void bhwp_fmt_set_verdict(const bhw_params *p, uint32_t dlog, int v)
 {
     std::lock_guard<std::mutex> lk(g_fmt_mu);
-    g_fmt_verdict[fmt_key(p, dlog)] = v;
+    if (v == kFmtOk || v == kFmtBad) g_fmt_verdict[fmt_key(p, dlog)] = v;
+    else g_fmt_verdict.erase(fmt_key(p, dlog));                  // anything else: forget it (unknown again)
 }
 
 uint64_t bhwp_table_scratch_bytes(const bhw_params *p, const BhwCordicCfg &c, bool tiled, uint32_t limit, bool capturing)
@@ -763,7 +779,7 @@ int bhw_describe_plan(const bhw_params *p, uint64_t n0, uint64_t count, const bh
     if (period && c.tab_dlog == 0 && bhwk_runlength_applicable(c, w, nullptr))     // generate_impl's period(): dropped phase bits
         snprintf(combine, sizeof combine, "k_runlength_window<%u,%d,%s> (16-byte aligned output; else k_table_combine_fold_t)", p->n_terms,
                  mode_of(c, w), c.dat_width <= 16 ? "true" : "false");
-    const char *fmt = c.tab_dlog == 0 ? "plain" : c.tab_dlog == 6 ? "delta16" : c.tab_dlog >= 16 ? "nibble" : "residual";
+    const char *fmt = c.tab_dlog == 0 ? "plain" : c.tab_dlog == 6 ? "delta16" : c.tab_dlog >= kEscFlag ? "nibble+esc" : c.tab_dlog >= 16 ? "nibble" : "residual";
     snprintf(buf, len, "table[%s%s]: %s + %s%s", fmt, state, build, (period || t.images) ? combine : "k_table_combine",
              t.images ? " (image subset)" : period && count != (1ull << p->phi_width) ? " (+ k_table_combine / k_replicate on the rest)" : "");
     return BHW_OK;

@@ -20,14 +20,20 @@
 // ---- table formats (bhw_device.h documents the encodings) -----------------------------------------------------------------------
 constexpr uint32_t kPackLog = 6;                // cfg.tab_dlog = 6: delta16
 constexpr uint32_t kNibbleFlag = 16;            // cfg.tab_dlog = kNibbleFlag + d: nibble; d = 7..9 alone: residual; 0: plain
+constexpr uint32_t kEscFlag = 32;               // cfg.tab_dlog = kEscFlag + kNibbleFlag + d: nibble with escapes (format 5)
+constexpr uint32_t kEscSlots = 128;             // escape table of one build workgroup: open addressing, one int4 {entry, c, s, -} per slot
+constexpr uint32_t kEscFill = 96;               // ... entries it may hold before the format is refused (cpp at 2^26 / 32 bits: 1 005 in all, at most 66 in one)
 BHW_HD constexpr uint32_t fmt_cell_log(uint32_t tab_dlog) { return tab_dlog & (kNibbleFlag - 1u); }
-BHW_HD constexpr int fmt_of(uint32_t tab_dlog) { return tab_dlog == 0 ? 0 : tab_dlog == kPackLog ? 1 : tab_dlog >= kNibbleFlag ? 3 : 2; }
+BHW_HD constexpr int fmt_of(uint32_t tab_dlog) { return tab_dlog == 0 ? 0 : tab_dlog == kPackLog ? 1 : tab_dlog >= kEscFlag ? 5 : tab_dlog >= kNibbleFlag ? 3 : 2; }
+
+BHW_HD constexpr bool fmt_is_resid(int fmt) { return fmt == 2 || fmt == 3 || fmt == 5; }     // straight-line records + a deviation per entry
+BHW_HD constexpr bool fmt_is_nibble(int fmt) { return fmt == 3 || fmt == 5; }               // ... in one byte, natural layout
 
 // The layout goes with the format: nibble tables are always in the natural order (resid_offset), whatever the caller asked for.
 inline BhwCordicCfg table_layout(const BhwCordicCfg &c)
 {
     BhwCordicCfg n = c;
-    if (fmt_of(c.tab_dlog) == 3) n.tab_split = 0u;
+    if (fmt_of(c.tab_dlog) == 3 || fmt_of(c.tab_dlog) == 5) n.tab_split = 0u;
     return n;
 }
 
@@ -35,6 +41,8 @@ inline BhwCordicCfg table_layout(const BhwCordicCfg &c)
 // 256-byte aligned.  bytes = what a call in this format needs.
 struct BhwTableLayout {
     uint64_t coarse_off, check_off, bytes;
+    uint64_t esc_off;       // nibble + escapes: the per-workgroup escape lists (0 otherwise)
+    uint32_t esc_wg_log;    // ... log2 of the entries one build workgroup owns
 };
 BhwTableLayout bhwp_table_layout(uint64_t entries, uint32_t tab_dlog);
 
@@ -83,7 +91,7 @@ int  bhwp_check_exec(const bhw_exec *ex);
 uint32_t bhwp_exec_table_format(const bhw_exec *ex);
 
 // Table formats a tiled whole-period call may use, narrowest first (tab_dlog values); plain (0) is always the last one.
-constexpr int kMaxFormats = 4;
+constexpr int kMaxFormats = 5;
 int bhwp_table_format_candidates(const BhwCordicCfg &c, bool tiled, uint32_t limit, uint32_t out[kMaxFormats]);
 // verdict cache of the packed formats: a property of (model, PW, W, PRECISION, format), settled on the device once per process
 enum { kFmtUnknown = 0, kFmtOk = 1, kFmtBad = 2 };

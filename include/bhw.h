@@ -97,7 +97,9 @@ enum {
     BHW_TABLE_PLAIN    = 1, /* int2 (c, s) per entry, 8 bytes                                       */
     BHW_TABLE_DELTA16  = 2, /* at most: 4 bytes per entry (int16 differences to a 64-entry block head) */
     BHW_TABLE_RESIDUAL = 3, /* at most: 2 bytes per entry against a linear predictor (8-bit fields) */
-    BHW_TABLE_NIBBLE   = 4  /* at most: 1 byte per entry, the same predictor with 4-bit fields (what BEST tries first) */
+    BHW_TABLE_NIBBLE   = 4, /* at most: 1 byte per entry, the same predictor with 4-bit fields (what BEST tries first) */
+    BHW_TABLE_NIBBLE_ESC = 5 /* at most: the same one-byte entries with a marker for the rare deviation beyond the fields, listed exactly
+                                beside the table (second choice of BEST: models whose CORDIC noise is wider, cpp / VHDL at 32 bits)  */
 };
 
 /* Optional execution controls for the *_ex entry points. */

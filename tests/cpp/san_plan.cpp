@@ -54,7 +54,7 @@ static void sweep_config(bhw_params &p, int parts)
             memset(&ex, 0, sizeof ex);
             ex.struct_size = sizeof ex;
             ex.algo = algo;
-            for (uint32_t limit = 0; limit <= (algo == BHW_ALGO_TABLE ? (uint32_t)BHW_TABLE_NIBBLE : 0u); ++limit) {
+            for (uint32_t limit = 0; limit <= (algo == BHW_ALGO_TABLE ? (uint32_t)BHW_TABLE_NIBBLE_ESC : 0u); ++limit) {
                 ex.table_format = limit;
                 const uint64_t tight = bhw_workspace_bytes_ex(&p, sh[0], sh[1], &ex), bound = bhw_workspace_bytes(&p, sh[0], sh[1], algo);
                 REQUIRE(tight <= bound && (bound == 0 || bound == E * 8), "scratch %" PRIu64 " > bound %" PRIu64, tight, bound);
@@ -73,7 +73,7 @@ static void sweep_config(bhw_params &p, int parts)
         if (tiled && !bhwk_tile_applicable(c, w)) continue;
         BhwCordicCfg ct = c;
         ct.tab_split = (tiled && c.z_shr == 0) ? 1u : 0u;
-        for (uint32_t limit = 0; limit <= BHW_TABLE_NIBBLE; ++limit) {
+        for (uint32_t limit = 0; limit <= BHW_TABLE_NIBBLE_ESC; ++limit) {
             uint32_t cand[kMaxFormats];
             const int n = bhwp_table_format_candidates(ct, tiled != 0, limit, cand);
             REQUIRE(n >= 1 && n <= kMaxFormats && cand[n - 1] == 0, "candidates %d", n);
@@ -83,6 +83,12 @@ static void sweep_config(bhw_params &p, int parts)
                 REQUIRE(l.bytes <= E * 8 || E < 64, "format %u needs %" PRIu64 " > 8E", cand[i], l.bytes);
                 REQUIRE(cand[i] == 0 || (l.coarse_off < l.check_off && l.check_off + 8 <= l.bytes && (l.coarse_off & 255) == 0 && (l.check_off & 255) == 0), "layout of %u", cand[i]);
                 REQUIRE(i == 0 || l.bytes >= prev, "candidates not narrowest first");
+                if (fmt_of(cand[i]) == 5) {                       // escape tables: one per build workgroup, between the records and the check word
+                    const uint64_t n_wg = ((E >> 1) + (1ull << l.esc_wg_log) - 1) >> l.esc_wg_log;
+                    REQUIRE(l.esc_off >= l.coarse_off + (E >> fmt_cell_log(cand[i])) * 16 && (l.esc_off & 255) == 0 && l.esc_off + n_wg * kEscSlots * 16 <= l.check_off,
+                            "escape tables of %u", cand[i]);
+                    REQUIRE((1u << (l.esc_wg_log - 6)) == bhwk_build_mirror_threads((uint32_t)E) / 4u, "escape tables per build workgroup");
+                } else REQUIRE(l.esc_off == 0, "escape tables in format %u", cand[i]);
                 prev = l.bytes;
                 if (cand[i]) {
                     BhwCordicCfg cf = ct;

@@ -187,7 +187,10 @@ def test_packed_format_overflow_is_detected_on_the_device(torch):
     for win, pw, w, model, dlog, expect in [(7, 26, 32, B.MODEL_HLS, 9, 0), (7, 26, 32, B.MODEL_CPP, 9, 0), (7, 24, 32, B.MODEL_HLS, 6, 0),
                                             (7, 22, 32, B.MODEL_HLS, 6, 1), (7, 22, 32, B.MODEL_HLS, 9, 1), (4, 22, 24, B.MODEL_VHDL, 9, 0),
                                             # 4-bit fields (16 + d): the HLS model's deviations stay within -5 .. 6, the cpp model's reach 10
-                                            (7, 26, 32, B.MODEL_HLS, 16 + 9, 0), (7, 26, 32, B.MODEL_CPP, 16 + 9, 1)]:
+                                            (7, 26, 32, B.MODEL_HLS, 16 + 9, 0), (7, 26, 32, B.MODEL_CPP, 16 + 9, 1),
+                                            # ... which the escape tables (48 + d) hold: 1 005 entries, at most 66 per build workgroup; cells of
+                                            # 2^9 entries at 2^24 / 32 bits put the curvature on top and overflow the tables
+                                            (7, 26, 32, B.MODEL_CPP, 48 + 9, 0), (7, 26, 32, B.MODEL_VHDL, 48 + 9, 0), (7, 24, 32, B.MODEL_CPP, 48 + 9, 1)]:
         p = B.make_params(win, pw, w, model=model)
         ws = torch.empty(B.lib().bhw_workspace_bytes(ctypes.byref(p), 0, 1 << pw, B.ALGO_TABLE), dtype=torch.uint8, device="cuda")
         assert L.bhw_dbg_check_table_format(ctypes.byref(p), 0, None, dlog, ctypes.c_void_p(ws.data_ptr()), ctypes.byref(flag)) == 0
@@ -203,15 +206,21 @@ def test_overflowing_format_falls_back_and_stays_exact(torch):
     assert L.bhw_dbg_table_format_info(ctypes.byref(p), ctypes.byref(d), ctypes.byref(ok16)) == 0
     assert d.value >= 7 and ok16.value == 1
     nib = 16 + d.value                                                                   # the 4-bit form is tried first
-    assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), nib, 0) == 0                  # unknown so far
-    assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), d.value, 0) == 0
+    for k in (nib, 48 + d.value, d.value, 6):                                            # unknown so far (the fuzz tests draw random
+        assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), k, 3) == 0                # configurations: forget what they may have settled)
     want = O.generate_mt(O.from_bhw(p), 0, 1 << 22)
     assert np.array_equal(bhw.generate(p, 0, 1 << 22, algo=B.ALGO_TABLE).cpu().numpy(), want)
     v_nib = L.bhw_dbg_table_format_verdict(ctypes.byref(p), nib, 0)
     assert v_nib in (1, 2)                                                               # decided on first use, either way
     if v_nib == 1:
         assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), nib, 2) == 2              # pretend it overflowed
-        assert np.array_equal(bhw.generate(p, 0, 1 << 22, algo=B.ALGO_TABLE).cpu().numpy(), want)   # 8-bit fields now
+        assert np.array_equal(bhw.generate(p, 0, 1 << 22, algo=B.ALGO_TABLE).cpu().numpy(), want)   # 4-bit fields + escape tables now
+    esc = 48 + d.value
+    v_esc = L.bhw_dbg_table_format_verdict(ctypes.byref(p), esc, 0)
+    assert v_esc in (1, 2)                                                               # decided when the plain nibbles were refused
+    if v_esc != 2:
+        assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), esc, 2) == 2              # pretend its tables overflowed
+    assert np.array_equal(bhw.generate(p, 0, 1 << 22, algo=B.ALGO_TABLE).cpu().numpy(), want)       # 8-bit fields now
     assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), d.value, 0) == 1              # verified exact on first use
     assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), d.value, 2) == 2              # pretend it overflowed
     assert np.array_equal(bhw.generate(p, 0, 1 << 22, algo=B.ALGO_TABLE).cpu().numpy(), want)   # delta16 now
@@ -221,13 +230,14 @@ def test_overflowing_format_falls_back_and_stays_exact(torch):
     assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), d.value, 1) == 1
     assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), 6, 1) == 1
     assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), nib, v_nib) == v_nib
+    assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), esc, v_esc) == v_esc
 
 
 def test_best_format_per_model(torch):
-    """BEST resolves to one byte per entry for the HLS model of the headline window and to two for the cpp model, whose
-    deviations do not fit four bits (decided by the device-side check of the first build, then cached)."""
+    """BEST resolves to one byte per entry for the HLS model of the headline window, and to one byte plus the escape tables for
+    the cpp model, whose deviations do not all fit four bits (decided by the device-side check of the first build, then cached)."""
     import blackman_harris_win_amd as bhw
-    for model, want in ((B.MODEL_HLS, "table[nibble]"), (B.MODEL_CPP, "table[residual]")):
+    for model, want in ((B.MODEL_HLS, "table[nibble]"), (B.MODEL_CPP, "table[nibble+esc]")):
         p = B.make_params(7, 26, 32, model=model)
         bhw.generate(p, 0, 1 << 26, algo=B.ALGO_TABLE)
         assert B.describe_plan(p, 0, 1 << 26, algo=B.ALGO_TABLE).startswith(want), B.describe_plan(p, 0, 1 << 26, algo=B.ALGO_TABLE)

@@ -594,17 +594,46 @@ def test_c3_full_64m(torch, golden):
 
 
 def test_packed_table_is_exact(torch, golden):
-    """The packed tables -- "nibble" / "residual" (1 / 2 bytes per entry against a linear predictor) and "delta16" (int16 differences
-    to the first entry of each 64-entry block) -- must give the same coefficients as the plain int2 table (bhw_exec.table_format)."""
+    """The packed tables -- "nibble" / "nibble + escapes" / "residual" (1 / 1 / 2 bytes per entry against a linear predictor) and
+    "delta16" (int16 differences to the first entry of each 64-entry block) -- must give the same coefficients as the plain int2
+    table (bhw_exec.table_format)."""
     import blackman_harris_win_amd as bhw
     for win, pw, w, model in ((7, 26, 32, 0), (7, 24, 32, 1), (4, 22, 24, 2), (5, 23, 29, 0), (7, 22, 28, 2), (3, 22, 30, 0),
-                              (7, 22, 32, 0), (7, 25, 26, 1)):
+                              (7, 22, 32, 0), (7, 25, 26, 1), (7, 26, 32, 1), (7, 26, 32, 2), (5, 25, 31, 1), (7, 24, 24, 2)):
         p = B.make_params(win, pw, w, model=model)
-        outs = [bhw.generate(p, 12345, (1 << pw) + 99999, algo=B.ALGO_TABLE, table_format=f)
-                for f in (B.TABLE_PLAIN, B.TABLE_DELTA16, B.TABLE_RESIDUAL, B.TABLE_NIBBLE, B.TABLE_BEST)]
+        # a ragged head, one whole period (the tile kernel over the packed table) and a ragged tail (the general gather over the same table)
+        outs = [bhw.generate(p, (1 << pw) - 12345, (1 << pw) + 12345 + 999, algo=B.ALGO_TABLE, table_format=f)
+                for f in (B.TABLE_PLAIN, B.TABLE_DELTA16, B.TABLE_RESIDUAL, B.TABLE_NIBBLE_ESC, B.TABLE_NIBBLE, B.TABLE_BEST)]
         for o in outs[1:]:
             assert bool((o == outs[0]).all()), (win, pw, w, model)
         del outs
+
+
+def test_nibble_escape_tables_in_every_tile_path(torch):
+    """The cpp model at 2^24 / 32 bits: CORDIC noise a little wider than the nibble fields, so BEST settles on nibble + escapes (one
+    byte per entry, a marker for the deviation that does not fit, the exact pair in the build workgroup's hash table).  Every kernel
+    that reads the table must resolve the marker: the 15-run tiles of a whole window, the masked instance of an image subset, the
+    part instances, the fused apply and the general gather of ragged ends -- all against the plain table, itself against the oracle."""
+    import blackman_harris_win_amd as bhw
+    p = B.make_params(7, 24, 32, model=B.MODEL_CPP)
+    n = 1 << 24
+    plain = bhw.generate(p, 0, n, algo=B.ALGO_TABLE, table_format=B.TABLE_PLAIN)
+    for a in (0, n // 2 - 4096, n - 8192):
+        assert np.array_equal(plain[a:a + 8192].cpu().numpy(), O.generate_mt(O.from_bhw(p), a, 8192))
+    full = bhw.generate(p, 0, n, algo=B.ALGO_TABLE)
+    assert B.describe_plan(p, 0, n, algo=B.ALGO_TABLE).startswith("table[nibble+esc]"), B.describe_plan(p, 0, n, algo=B.ALGO_TABLE)
+    assert bool((full == plain).all())
+    for n0, count in ((n // 8, n // 4), (5 * (n // 8), 3 * (n // 8)), (n - 777, n + 777 + 55)):
+        sh = bhw.generate(p, n0, count, algo=B.ALGO_TABLE, table_format=B.TABLE_NIBBLE_ESC)
+        idx = (torch.arange(count, device="cuda") + n0) % n
+        assert bool((sh == plain[idx]).all()), (n0, count)
+    window = torch.zeros(n, dtype=torch.int32, device="cuda")
+    for part in range(3):
+        bhw.generate_part(p, part, 3, window, algo=B.ALGO_TABLE, table_format=B.TABLE_NIBBLE_ESC)
+    assert bool((window == plain).all())
+    x = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int32, device="cuda")
+    y = bhw.apply(p, x, shift=31)
+    assert bool((((x.to(torch.int64) * plain.to(torch.int64)) >> 31).to(torch.int32) == y).all())
 
 
 def test_c3_full_64m_model_cpp(torch, golden):

@@ -342,6 +342,34 @@ def test_residual_format_margin():
     assert 0 < worst <= 40, worst
 
 
+def test_nibble_escape_capacity():
+    """The "nibble + escapes" table format (csrc/bhw_device.h, format 5): one byte per entry, the deviation from the residual format's
+    straight line in two 4-bit fields, the low field -8 reserved as the marker of an entry listed exactly in the hash table of the
+    build workgroup that stores it (128 slots, at most 96 used; a workgroup owns 2^14 entries of [0, E/2) and their images E - u for
+    tables of 2^24 entries).  Measured here over the WHOLE table of the headline window for the two models whose noise is wider
+    than the fields: about 1 000 .. 1 500 listed entries of 2^24 (6 .. 9 per 100 000), the fullest workgroup well inside its table."""
+    pw, w, d = 26, 32, 9
+    E = 1 << (pw - 2)
+    own = 1 << 14
+    for model, lo, hi in ((O.MODEL_CPP, 900, 1100), (O.MODEL_VHDL, 1300, 1700)):
+        s, c = O.sincos(O.oparams(1, pw, w, model=model), 0, E + 1)
+        s, c = s.astype(np.int64), c.astype(np.int64)
+        f = np.arange(1 << d, dtype=np.int64)
+        hc, hs = c[::1 << d], s[::1 << d]
+        dc = c[:E].reshape(-1, 1 << d) - (hc[:-1, None] + (((hc[1:] - hc[:-1])[:, None] * f) >> d))
+        ds = s[:E].reshape(-1, 1 << d) - (hs[:-1, None] + (((hs[1:] - hs[:-1])[:, None] * f) >> d))
+        assert max(int(np.abs(dc).max()), int(np.abs(ds).max())) > 7                       # four-bit fields alone do not hold it
+        esc = ((dc < -7) | (dc > 7) | (ds < -8) | (ds > 7)).reshape(-1)                    # dc == -8 is the marker itself
+        total = int(esc.sum())
+        assert lo <= total <= hi, (model, total)
+        per_own = esc[:E // 2].reshape(-1, own).sum(axis=1)
+        per_img = esc[E // 2 + 1:][::-1].reshape(-1)[:E // 2 - 1]                         # image E - u of source u = 1 .. E/2 - 1
+        per_img = np.concatenate([[0], per_img]).reshape(-1, own).sum(axis=1)
+        per_wg = per_own + per_img
+        per_wg[-1] += int(esc[E // 2])                                                     # the middle entry: the last workgroup
+        assert int(per_wg.sum()) == total and int(per_wg.max()) <= 96, (model, int(per_wg.max()))
+
+
 def test_quadrant_images_share_first_quadrant_result():
     """cos/sin at theta + j*N/4 are the quadrant-rotated first-quadrant pair (basis of the table strategy)."""
     for model in (O.MODEL_HLS, O.MODEL_CPP, O.MODEL_VHDL):

@@ -32,11 +32,11 @@ def fuzz(budget=60.0, seed=1, max_cases=None, pws=(22, 22, 23, 23, 24, 24, 25, 2
         except B.BhwError:
             continue
         n = 1 << pw
-        fmt = int(rng.choice([B.TABLE_BEST, B.TABLE_BEST, B.TABLE_NIBBLE, B.TABLE_RESIDUAL, B.TABLE_DELTA16, B.TABLE_PLAIN]))
+        fmt = int(rng.choice([B.TABLE_BEST, B.TABLE_BEST, B.TABLE_NIBBLE, B.TABLE_NIBBLE_ESC, B.TABLE_RESIDUAL, B.TABLE_DELTA16, B.TABLE_PLAIN]))
         if rng.random() < 0.2:                                          # a configuration class whose deviations fit four bits
             model, combine_keep = B.MODEL_HLS, combine
             w = int(rng.integers(max(28, pw + 4), 33)) if pw + 4 <= 32 else 32
-            fmt = int(rng.choice([B.TABLE_BEST, B.TABLE_NIBBLE]))
+            fmt = int(rng.choice([B.TABLE_BEST, B.TABLE_NIBBLE, B.TABLE_NIBBLE_ESC]))
             p = B.make_params(win, pw, w, model=model, combine=combine_keep, precision=1,
                               aa=None if aa is None else [max(-(1 << (w - 1)), min((1 << (w - 1)) - 1, v)) for v in aa])
         n0 = n * int(rng.integers(0, 3)) if rng.random() < 0.7 else int(rng.integers(0, 4 * n))
