@@ -569,6 +569,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 const uint32_t tp = t ? t - 1u : n_cell[w] + 1u;     // last cell of the table: slope of the cell before it
                 r = make_int4(hc[w][t], hs[w][t], hc[w][t] - hc[w][tp], hs[w][t] - hs[w][tp]);
             }
+            if constexpr (FMT == 5) { r.x += (int32_t)kEscBias; r.y += (int32_t)kEscBias; }   // the line the deviations are centred on
             hrec[w][t] = r;
             if ((cell << d) >= r_lo[w])                              // its first entry is stored by this workgroup
                 reinterpret_cast<int4 *>(const_cast<void *>(plan.tab_coarse))[cell] = r;

@@ -106,9 +106,9 @@ __device__ __forceinline__ uint32_t tab_index(uint32_t u, uint32_t log2_entries,
 //          configuration (a model whose noise is wider -- the cpp model reaches 10 -- falls back to the byte fields).
 //   55..57 "nibble + escapes" (48 + d): the nibble format with the low field -8 reserved as a marker: that entry's exact pair is in
 //          the hash table (kEscSlots slots, esc_lookup) of the build workgroup that stored it, at cfg.tab_esc.  For the models whose
-//          noise is a little wider than the fields -- cpp, VHDL at 32 bits: about 1 000 / 1 500 of the 2^24 entries of a 2^26-point
-//          window, at most 66 / 75 in one workgroup (tests/test_oracle.py::test_nibble_escape_capacity) -- so that they too read one
-//          byte per entry.  The tile kernel tests the minimum of a harmonic's low fields (one v_min per gather, one branch per
+//          noise is a little wider than the fields -- cpp, VHDL at 32 bits: 547 / 932 of the 2^24 entries of a 2^26-point
+//          window, at most 36 / 74 in one workgroup (tests/test_oracle.py::test_nibble_escape_capacity; the records of this format
+//          carry c + 1, s + 1, which centres the deviations and halves the count) -- so that they too read one byte per entry.  The tile kernel tests the minimum of a harmonic's low fields (one v_min per gather, one branch per
 //          harmonic) and resolves the rare marked lane on the scalar unit (esc_fix_wave); a workgroup whose table would fill
 //          beyond kEscFill sets the check word and the configuration falls back to the byte fields.
 // The combine pass is bound by table + output traffic as much as by arithmetic, and these cut the table's share to 1/2 .. 1/8.
@@ -146,8 +146,8 @@ struct ResidK {
 
 // Nibble + escapes: the entry whose low field holds the marker -8 is listed exactly.  Entry u of [0, E) was stored by the build
 // workgroup that owns its source min(u, E - u) (the middle entry E/2 by the last one); that workgroup's list is a hash table of
-// kEscSlots slots { u or -1, c, s, - }, open addressing from esc_slot(u).  A few entries per million (the cpp model at 2^26 /
-// 32 bits: 1 005 of 2^24), at most kEscFill per workgroup: one or two probes, and the branch that leads here is cold.
+// kEscSlots slots { u or -1, c, s, - }, open addressing from esc_slot(u).  A few entries per 100 000 (the cpp model at 2^26 /
+// 32 bits: 547 of 2^24), at most kEscFill per workgroup: one or two probes, and the branch that leads here is cold.
 constexpr uint32_t kEscMarker = 8u;
 __device__ __forceinline__ uint32_t esc_slot(uint32_t u) { return (u * 0x9E3779B1u) >> 25; }
 static_assert(kEscSlots == 128, "esc_slot: seven bits");

@@ -22,7 +22,8 @@ constexpr uint32_t kPackLog = 6;                // cfg.tab_dlog = 6: delta16
 constexpr uint32_t kNibbleFlag = 16;            // cfg.tab_dlog = kNibbleFlag + d: nibble; d = 7..9 alone: residual; 0: plain
 constexpr uint32_t kEscFlag = 32;               // cfg.tab_dlog = kEscFlag + kNibbleFlag + d: nibble with escapes (format 5)
 constexpr uint32_t kEscSlots = 128;             // escape table of one build workgroup: open addressing, one int4 {entry, c, s, -} per slot
-constexpr uint32_t kEscFill = 96;               // ... entries it may hold before the format is refused (cpp at 2^26 / 32 bits: 1 005 in all, at most 66 in one)
+constexpr uint32_t kEscBias = 1;                // ... records carry c + 1, s + 1: the chord of a concave arc lies below it, and the deviations lean positive
+constexpr uint32_t kEscFill = 96;               // ... entries it may hold before the format is refused (cpp at 2^26 / 32 bits: 547 in all, at most 36 in one)
 BHW_HD constexpr uint32_t fmt_cell_log(uint32_t tab_dlog) { return tab_dlog & (kNibbleFlag - 1u); }
 BHW_HD constexpr int fmt_of(uint32_t tab_dlog) { return tab_dlog == 0 ? 0 : tab_dlog == kPackLog ? 1 : tab_dlog >= kEscFlag ? 5 : tab_dlog >= kNibbleFlag ? 3 : 2; }
 

@@ -188,7 +188,7 @@ def test_packed_format_overflow_is_detected_on_the_device(torch):
                                             (7, 22, 32, B.MODEL_HLS, 6, 1), (7, 22, 32, B.MODEL_HLS, 9, 1), (4, 22, 24, B.MODEL_VHDL, 9, 0),
                                             # 4-bit fields (16 + d): the HLS model's deviations stay within -5 .. 6, the cpp model's reach 10
                                             (7, 26, 32, B.MODEL_HLS, 16 + 9, 0), (7, 26, 32, B.MODEL_CPP, 16 + 9, 1),
-                                            # ... which the escape tables (48 + d) hold: 1 005 entries, at most 66 per build workgroup; cells of
+                                            # ... which the escape tables (48 + d) hold: 547 entries, at most 36 per build workgroup; cells of
                                             # 2^9 entries at 2^24 / 32 bits put the curvature on top and overflow the tables
                                             (7, 26, 32, B.MODEL_CPP, 48 + 9, 0), (7, 26, 32, B.MODEL_VHDL, 48 + 9, 0), (7, 24, 32, B.MODEL_CPP, 48 + 9, 1)]:
         p = B.make_params(win, pw, w, model=model)

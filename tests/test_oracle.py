@@ -346,19 +346,21 @@ def test_nibble_escape_capacity():
     """The "nibble + escapes" table format (csrc/bhw_device.h, format 5): one byte per entry, the deviation from the residual format's
     straight line in two 4-bit fields, the low field -8 reserved as the marker of an entry listed exactly in the hash table of the
     build workgroup that stores it (128 slots, at most 96 used; a workgroup owns 2^14 entries of [0, E/2) and their images E - u for
-    tables of 2^24 entries).  Measured here over the WHOLE table of the headline window for the two models whose noise is wider
-    than the fields: about 1 000 .. 1 500 listed entries of 2^24 (6 .. 9 per 100 000), the fullest workgroup well inside its table."""
+    tables of 2^24 entries).  The records of this format carry c + 1, s + 1 (kEscBias: the deviations lean positive).  Measured here
+    over the WHOLE table of the headline window for the two models whose noise is wider than the fields: 547 / 932 listed entries of
+    2^24 (3 .. 6 per 100 000; 1 005 / 1 486 without the bias), the fullest workgroup inside its table."""
     pw, w, d = 26, 32, 9
     E = 1 << (pw - 2)
     own = 1 << 14
-    for model, lo, hi in ((O.MODEL_CPP, 900, 1100), (O.MODEL_VHDL, 1300, 1700)):
+    for model, lo, hi in ((O.MODEL_CPP, 450, 650), (O.MODEL_VHDL, 800, 1100)):
         s, c = O.sincos(O.oparams(1, pw, w, model=model), 0, E + 1)
         s, c = s.astype(np.int64), c.astype(np.int64)
         f = np.arange(1 << d, dtype=np.int64)
         hc, hs = c[::1 << d], s[::1 << d]
         dc = c[:E].reshape(-1, 1 << d) - (hc[:-1, None] + (((hc[1:] - hc[:-1])[:, None] * f) >> d))
         ds = s[:E].reshape(-1, 1 << d) - (hs[:-1, None] + (((hs[1:] - hs[:-1])[:, None] * f) >> d))
-        assert max(int(np.abs(dc).max()), int(np.abs(ds).max())) > 7                       # four-bit fields alone do not hold it
+        assert max(int(np.abs(dc).max()), int(np.abs(ds).max())) > 8                       # four-bit fields alone do not hold it
+        dc, ds = dc - 1, ds - 1                                                            # kEscBias
         esc = ((dc < -7) | (dc > 7) | (ds < -8) | (ds > 7)).reshape(-1)                    # dc == -8 is the marker itself
         total = int(esc.sum())
         assert lo <= total <= hi, (model, total)
