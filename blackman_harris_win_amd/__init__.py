@@ -15,7 +15,7 @@ The surface mirrors the reference's operator:
 """
 from .binding import (  # noqa: F401
     ALGO_AUTO, ALGO_DIRECT, ALGO_FUSED, ALGO_TABLE,
-    TABLE_BEST, TABLE_DELTA16, TABLE_NIBBLE, TABLE_PLAIN, TABLE_RESIDUAL,
+    TABLE_BEST, TABLE_DELTA16, TABLE_NIBBLE, TABLE_NIBBLE_ESC, TABLE_PLAIN, TABLE_RESIDUAL,
     COMBINE_HLS, COMBINE_VHDL,
     MODEL_CPP, MODEL_DDS48, MODEL_HLS, MODEL_SCALED, MODEL_VHDL,
     SIN_CORDIC, SIN_TAYLOR, SIN_TAYLOR_ALL,
