@@ -589,7 +589,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
         if constexpr (FMT == 5) {
             // the deviation that does not fit (or collides with the marker) goes to this workgroup's list, the marker into the table
             uint32_t v = ((uint32_t)dc & 0xFu) | ((uint32_t)ds << 4);
-            if (__builtin_expect(!(fits_bits(dc, 4) && fits_bits(ds, 4)) || dc == -8, 0)) {
+            // (both tests evaluated, then OR-ed: a short-circuit && made the compiler fetch the record's second half and form ds inside a branch)
+            const uint32_t w1 = (uint32_t)(dc + 7), w2 = (uint32_t)(ds + 8);                    // dc in -7 .. 7 (-8 is the marker), ds in -8 .. 7
+            if (__builtin_expect((int)(w1 > 14u) | (int)(w2 > 15u), 0)) {
                 const uint32_t slot = atomicAdd(&esc_n, 1u);
                 if (slot < kEscFill) esc_list[slot] = make_int4((int32_t)idx, c, sn, 0);    // (beyond: the format is refused below)
                 v = kEscMarker;
