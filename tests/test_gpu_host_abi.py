@@ -118,6 +118,29 @@ def test_prepare_then_graph_capture_without_workspace(torch):
             assert np.array_equal(out_y.cpu().numpy(), O.generate_mt(O.from_bhw(py), 777, 1 << 15))
 
 
+def test_prepare_settles_the_escape_format_for_capture(torch):
+    """The cpp model at 2^24 / 32 bits: plain nibbles are refused, nibble + escapes holds.  bhw_prepare_device settles both verdicts,
+    so a captured call builds the escape tables inside the graph (no read-back) and its replays match the oracle."""
+    import blackman_harris_win_amd as bhw
+    p = B.make_params(7, 24, 32, model=B.MODEL_CPP)
+    n = 1 << 24
+    want = O.generate_mt(O.from_bhw(p), 0, n)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        out = torch.zeros(n, dtype=torch.int32, device="cuda")
+        bhw.prepare(p)
+        assert B.describe_plan(p, 0, n, algo=B.ALGO_TABLE).startswith("table[nibble+esc]:"), B.describe_plan(p, 0, n, algo=B.ALGO_TABLE)
+        st.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st):
+            bhw.generate(p, 0, n, out=out, algo=B.ALGO_TABLE)
+        for _ in range(2):
+            out.zero_()
+            graph.replay()
+            st.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want)
+
+
 def test_prepare_covers_table_calls_of_fused_size_windows(torch):
     """Round-3 advisor finding: bhw_prepare_device skipped the scratch when AUTO sends the WHOLE period to the fused kernel, yet a
     partial range of such a window (no whole period -> table strategy) or an explicit BHW_ALGO_TABLE still builds a table; inside
