@@ -735,7 +735,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 }
             }
         }
-        const uint32_t idx = idx_a + g * idx_m;
+        // (nibble tables are always in the natural order: scalar shift + one add instead of the 64-bit multiply-add of the general form)
+        const uint32_t idx = fmt_is_nibble(FMT) ? (g << 6) + lane : idx_a + g * idx_m;
         store_entry(idx, c1, s1, record(0, g6 >> d), (g6 & fmask) + lane);
         if (has_image && !deferred) {
             // images E - 64g - 63 .. E - 64g, descending with the lane: one cell, or two when lane 0's image opens the next one
@@ -747,7 +748,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 const int4 rb = record(1, cell_b);
                 if (lane == 0u) rec2 = rb;
             }
-            store_entry(idx_i - idx, c2, s2, rec2, um & fmask);
+            store_entry(fmt_is_nibble(FMT) ? E - idx : idx_i - idx, c2, s2, rec2, um & fmask);
         }
     }
     BHW_STAMP_MIN(3);                                                // first wave done with its groups
