@@ -63,7 +63,7 @@ def _write_stamp(target, digest):
         f.write(digest + "\n")
 
 
-KERNEL_UNITS = ("bhw_direct.hip", "bhw_build.hip", "bhw_combine.hip", "bhw_fused.hip", "bhw_taylor.hip", "bhw_variants.hip")
+KERNEL_UNITS = ("bhw_direct.hip", "bhw_build.hip", "bhw_combine.hip", "bhw_tile9.hip", "bhw_fused.hip", "bhw_taylor.hip", "bhw_variants.hip")
 HEADERS = ("bhw_internal.h", "bhw_plan.h", "bhw_device.h", "bhw_tables.inc")
 
 

@@ -570,7 +570,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
                 r = make_int4(hc[w][t], hs[w][t], hc[w][t] - hc[w][tp], hs[w][t] - hs[w][tp]);
             }
             if constexpr (FMT == 5) { r.x += (int32_t)kEscBias; r.y += (int32_t)kEscBias; }   // the line the deviations are centred on
+            if constexpr (fmt_is_nibble(FMT)) { r.x -= 8; r.y -= 8; }                         // the fields are stored unsigned: deviation + 8
             hrec[w][t] = r;
+            // (the table's copy of a nibble record carries the slopes doubled -- tab_predict_nib: the tile kernel evaluates the line with
+            // one v_mul_hi_i32 per coordinate; this kernel keeps the plain slopes and the shift by d it has in a register anyway)
+            if constexpr (fmt_is_nibble(FMT)) { r.z *= 2; r.w *= 2; }
             if ((cell << d) >= r_lo[w])                              // its first entry is stored by this workgroup
                 reinterpret_cast<int4 *>(const_cast<void *>(plan.tab_coarse))[cell] = r;
         }
@@ -584,23 +588,26 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
 
     // one entry: deviation from the record's straight line, checked and packed
     auto store_entry = [&](uint32_t idx, int32_t c, int32_t sn, const int4 rec, uint32_t pos) {
-        const int2 p = tab_predict(rec, pos, d);
-        const int32_t dc = c - p.x, ds = sn - p.y;
         if constexpr (FMT == 5) {
             // the deviation that does not fit (or collides with the marker) goes to this workgroup's list, the marker into the table
-            uint32_t v = ((uint32_t)dc & 0xFu) | ((uint32_t)ds << 4);
+            const int2 p = tab_predict(rec, pos, d);                                            // (hrec: plain slopes)
+            const uint32_t nc = (uint32_t)(c - p.x), ns = (uint32_t)(sn - p.y);                 // the biased fields: deviation + 8
+            uint32_t v = nc | (ns << 4);
             // (both tests evaluated, then OR-ed: a short-circuit && made the compiler fetch the record's second half and form ds inside a branch)
-            const uint32_t w1 = (uint32_t)(dc + 7), w2 = (uint32_t)(ds + 8);                    // dc in -7 .. 7 (-8 is the marker), ds in -8 .. 7
-            if (__builtin_expect((int)(w1 > 14u) | (int)(w2 > 15u), 0)) {
+            if (__builtin_expect((int)(nc - 1u > 14u) | (int)(ns > 15u), 0)) {                   // dev_c in -7 .. 7 (-8 is the marker), dev_s in -8 .. 7
                 const uint32_t slot = atomicAdd(&esc_n, 1u);
                 if (slot < kEscFill) esc_list[slot] = make_int4((int32_t)idx, c, sn, 0);    // (beyond: the format is refused below)
                 v = kEscMarker;
             }
             table_store<1>(table, idx, v);
         } else if constexpr (FMT == 3) {
-            if (plan.check_flag && !(fits_bits(dc, 4) && fits_bits(ds, 4))) atomicOr(plan.check_flag, 1u);
-            table_store<1>(table, idx, ((uint32_t)dc & 0xFu) | ((uint32_t)ds << 4));              // bits 8.. are not stored
+            const int2 p = tab_predict(rec, pos, d);                                            // (hrec: plain slopes)
+            const uint32_t nc = (uint32_t)(c - p.x), ns = (uint32_t)(sn - p.y);
+            if (plan.check_flag && (nc | ns) > 15u) atomicOr(plan.check_flag, 1u);
+            table_store<1>(table, idx, nc | (ns << 4));                                           // bits 8.. are not stored
         } else {
+            const int2 p = tab_predict(rec, pos, d);
+            const int32_t dc = c - p.x, ds = sn - p.y;
             if (plan.check_flag && !(fits_bits(dc, 8) && fits_bits(ds, 8))) atomicOr(plan.check_flag, 1u);
             table_store<2>(table, idx, ((uint32_t)dc & 0xFFu) | ((uint32_t)ds << 8));           // bits 16.. are not stored
         }

@@ -398,7 +398,7 @@ __global__ __launch_bounds__(tile_wg_of(NB)) __attribute__((amdgpu_waves_per_eu(
         constexpr int NG = (K & 1) ? 2 : 1;                                                              \
         constexpr int KC = (K % 4 == 0) ? 4 : (K % 2 == 0) ? 2 : 0;   /* split layout only exists at z_shr == 0 */ \
         int2 cs[NR][NG];                                                                                 \
-        int32_t esc_min = 0;                                                                             \
+        uint32_t esc_min = ~0u;                                                                          \
         _Pragma("unroll") for (int b = B0; b < B1; ++b) {                                                 \
             _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                             \
                 if (MASKED && NG == 2 && !(g ? want1 : want0)) continue;                                 \
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(tile_wg_of(NB)) __attribute__((amdgpu_waves_per_eu(
                     }                                                                                    \
                     cs[b][g] = resid_value<FMT, LDS>(cfg, theta, emask_v, rk, lrec, bias, e);            \
                     if constexpr (FMT == 5) {                                                            \
-                        const int32_t dcv = (int32_t)(e << 28) >> 28;                                    \
+                        const uint32_t dcv = e << 28;               /* the low field, zero = the marker */ \
                         esc_min = dcv < esc_min ? dcv : esc_min;                                         \
                     }                                                                                    \
                 } else if constexpr (NB > 1 && (K & 1)) cs[b][g] = tab_load_class<FMT>(cfg, table, theta & emask_v, cls[b]); \
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(tile_wg_of(NB)) __attribute__((amdgpu_waves_per_eu(
         if constexpr (NB > 1 && FMT == 5) {                                                              \
             /* nibble + escapes: one test per harmonic (the minimum of its low fields is the marker); the listed entries are a few   \
                per million, so the branch is almost never taken and the loads of the next harmonic are not held up by six of them */ \
-            if (__builtin_expect(esc_min == -(int32_t)kEscMarker, 0)) {                                  \
+            if (__builtin_expect(esc_min == (kEscMarker << 28), 0)) {                                    \
                 _Pragma("unroll") for (int b = B0; b < B1; ++b) {                                         \
                     _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                     \
                         if (MASKED && NG == 2 && !(g ? want1 : want0)) continue;                         \
@@ -802,6 +802,7 @@ int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c_in, 
     const uint32_t wg_threads = (uint32_t)tile_wg_of(nb);
     const dim3 grid(tile_count * ((uint32_t)kTileThreads / wg_threads)), block(wg_threads);
     const bool fast = bhwp_tile_fast(c, w, nb);                     // one-instruction products (and, VHDL rule, one-word sums)
+    if (bhwk_tile9_applicable(c, w, nb, fast, masked)) return bhwk_tile9(l, c, w, tp, tile_count, d_table, d_out);   // bhw_tile9.hip
 #define BHW_LAUNCH_TILE_MFK(NB, M, F, K)                                                                                 \
     do {                                                                                                                 \
         if (c.tab_dlog == 0)             BHW_LAUNCH((k_table_combine_tile<NB, M, 0, F, K>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \

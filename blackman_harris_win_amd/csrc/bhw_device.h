@@ -100,15 +100,17 @@ __device__ __forceinline__ uint32_t tab_index(uint32_t u, uint32_t log2_entries,
 //          int4 records {c, s, dc, ds} at cfg.tab_coarse (16 bytes per 2^d entries).  Build and combine evaluate the same
 //          integer predictor  rec.c + ((rec.dc * (t mod 2^d)) >> d),  so the reconstruction is exact as long as the deviation
 //          fits int8 (tests/test_oracle.py::test_residual_format_margin measures <= 40 over every model and width).
-//   23..25 "nibble" (16 + d): the residual format with the two deviations in 4-bit fields, one byte per entry.  The deviations
+//   23..25 "nibble" (16 + d): the residual format with the two deviations in 4-bit fields, one byte per entry:
+//          byte = (dev_c + 8) | (dev_s + 8) << 4, both fields unsigned; the records of these formats are {c - 8, s - 8, 2 dc, 2 ds}
+//          (tab_predict_nib), so an entry is  record line + field  with no sign extension.  The deviations
 //          of the 32-bit HLS model stay within -5 .. 6 over the whole 2^24-entry table of a 2^26-point window (measured with the
 //          oracle); like the other packed formats it is used only after the build kernel has checked every entry of the
 //          configuration (a model whose noise is wider -- the cpp model reaches 10 -- falls back to the byte fields).
-//   55..57 "nibble + escapes" (48 + d): the nibble format with the low field -8 reserved as a marker: that entry's exact pair is in
+//   55..57 "nibble + escapes" (48 + d): the nibble format with the low field 0 (deviation -8) reserved as a marker: that entry's exact pair is in
 //          the hash table (kEscSlots slots, esc_lookup) of the build workgroup that stored it, at cfg.tab_esc.  For the models whose
 //          noise is a little wider than the fields -- cpp, VHDL at 32 bits: 547 / 932 of the 2^24 entries of a 2^26-point
 //          window, at most 36 / 74 in one workgroup (tests/test_oracle.py::test_nibble_escape_capacity; the records of this format
-//          carry c + 1, s + 1, which centres the deviations and halves the count) -- so that they too read one byte per entry.  The tile kernel tests the minimum of a harmonic's low fields (one v_min per gather, one branch per
+//          carry another + 1, which centres the deviations and halves the count) -- so that they too read one byte per entry.  The tile kernel tests the minimum of a harmonic's low fields (one v_min per gather, one branch per
 //          harmonic) and resolves the rare marked lane on the scalar unit (esc_fix_wave); a workgroup whose table would fill
 //          beyond kEscFill sets the check word and the configuration falls back to the byte fields.
 // The combine pass is bound by table + output traffic as much as by arithmetic, and these cut the table's share to 1/2 .. 1/8.
@@ -118,6 +120,16 @@ __device__ __forceinline__ int2 tab_predict(const int4 rec, uint32_t f, uint32_t
 {
     return make_int2(rec.x + (__mul24(rec.z, (int32_t)f) >> d), rec.y + (__mul24(rec.w, (int32_t)f) >> d));   // |dc|, |ds| < 2^17, f < 2^9
 }
+
+// Nibble formats (3, 5): the records hold the slopes DOUBLED and the start values less the fields' bias (see "nibble" above), so
+// that the tile kernel evaluates the line as one v_mul_hi_i32 per coordinate -- hi32(2 dc * (f << (31 - d))) = (dc * f) >> d
+// exactly -- and reads the fields as unsigned (an and and a shift, VOP2 at full rate, instead of two v_bfe_i32).  Everyone else
+// evaluates the same line here.
+__device__ __forceinline__ int2 tab_predict_nib(const int4 rec, uint32_t f, uint32_t d)
+{
+    return make_int2(rec.x + (__mul24(rec.z, (int32_t)f) >> (d + 1u)), rec.y + (__mul24(rec.w, (int32_t)f) >> (d + 1u)));   // |2 dc|, |2 ds| < 2^18, f < 2^9
+}
+__device__ __forceinline__ int2 nib_fields(uint32_t e) { return make_int2((int32_t)(e & 15u), (int32_t)((e >> 4) & 15u)); }
 
 // v representable as a two's-complement field of `bits` bits
 __device__ __forceinline__ bool fits_bits(int32_t v, uint32_t bits)
@@ -148,7 +160,7 @@ struct ResidK {
 // workgroup that owns its source min(u, E - u) (the middle entry E/2 by the last one); that workgroup's list is a hash table of
 // kEscSlots slots { u or -1, c, s, - }, open addressing from esc_slot(u).  A few entries per 100 000 (the cpp model at 2^26 /
 // 32 bits: 547 of 2^24), at most kEscFill per workgroup: one or two probes, and the branch that leads here is cold.
-constexpr uint32_t kEscMarker = 8u;
+constexpr uint32_t kEscMarker = 0u;                               // low field (biased by 8) of a listed entry: the deviation -8
 __device__ __forceinline__ uint32_t esc_slot(uint32_t u) { return (u * 0x9E3779B1u) >> 25; }
 static_assert(kEscSlots == 128, "esc_slot: seven bits");
 __device__ __forceinline__ int2 esc_lookup(const void *__restrict__ esc, uint32_t esc_wg_log, uint32_t log2_entries, uint32_t u)
@@ -206,14 +218,17 @@ __device__ __forceinline__ int2 tab_fetch(const BhwCordicCfg &cfg, const void *_
         return make_int2(base.x + (int32_t)(int16_t)(e & 0xFFFFu), base.y + ((int32_t)e >> 16));
     }
     const uint32_t d = fmt_cell_log(cfg.tab_dlog);
-    const int2 p = tab_predict(ld_off<int4>(cfg.tab_coarse, (u >> d) << 4), u & ((1u << d) - 1u), d);
+    const int4 rec = ld_off<int4>(cfg.tab_coarse, (u >> d) << 4);
     if (FMT == 3 || FMT == 5 || (FMT < 0 && cfg.tab_dlog >= kNibbleFlag)) {
+        const int2 p = tab_predict_nib(rec, u & ((1u << d) - 1u), d);
         const uint32_t e = ld_off<uint8_t>(table, idx);
         if (FMT == 5 || (FMT < 0 && cfg.tab_dlog >= kEscFlag)) {
             if ((e & 0xFu) == kEscMarker) return esc_lookup(cfg.tab_esc, cfg.esc_wg_log, cfg.phi_width - 2u, u);
         }
-        return make_int2(p.x + ((int32_t)(e << 28) >> 28), p.y + ((int32_t)(e << 24) >> 28));
+        const int2 n = nib_fields(e);
+        return make_int2(p.x + n.x, p.y + n.y);
     }
+    const int2 p = tab_predict(rec, u & ((1u << d) - 1u), d);
     const uint32_t e = ld_off<uint16_t>(table, idx << 1);
     return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
 }
@@ -230,12 +245,14 @@ __device__ __forceinline__ int2 resid_value(const BhwCordicCfg &cfg, uint32_t th
     int4 rec;
     if constexpr (LDS) rec = *reinterpret_cast<const int4 *>(lrec + (((theta >> rk.d) << 4) + bias));
     else rec = ld_off<int4>(cfg.tab_coarse, ((theta & emask) >> rk.d) << 4);
-    // (the predictor as two shifts + two v_mul_hi_i32 on doubled slopes -- one instruction fewer per gather -- measured slower:
-    // 0.1358 -> 0.1367 ms, profiles/r02_ab_tile_memory_path.txt)
-    const int2 p = tab_predict(rec, theta & rk.fmask, rk.d);
     // (FMT 5: the caller looks for the escape marker, once per harmonic -- BHW_TILE_HARMONIC)
-    if constexpr (FMT == 3 || FMT == 5) return make_int2(p.x + ((int32_t)(e << 28) >> 28), p.y + ((int32_t)(e << 24) >> 28));
-    else return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
+    if constexpr (FMT == 3 || FMT == 5) {
+        const int2 p = tab_predict_nib(rec, theta & rk.fmask, rk.d), n = nib_fields(e);
+        return make_int2(p.x + n.x, p.y + n.y);
+    } else {
+        const int2 p = tab_predict(rec, theta & rk.fmask, rk.d);
+        return make_int2(p.x + (int32_t)(int8_t)(e & 0xFFu), p.y + (int32_t)(int8_t)(e >> 8));
+    }
 }
 
 template <int KCLASS = 0, int FMT = -1, int SPLIT = -1>
@@ -323,12 +340,14 @@ __device__ __forceinline__ void tab_store(void *__restrict__ table, uint32_t u, 
         if ((u & ((1u << kPackLog) - 1u)) == 0u) reinterpret_cast<int2 *>(coarse)[u >> kPackLog] = make_int2(c, s);
     } else {
         const uint32_t d = fmt_cell_log(dlog);
-        const int2 p = tab_predict(rec, u & ((1u << d) - 1u), d);
-        const int32_t dc = c - p.x, ds = s - p.y;
         if (FMT == 3 || (FMT < 0 && dlog >= kNibbleFlag)) {
-            if (check_flag && !(fits_bits(dc, 4) && fits_bits(ds, 4))) atomicOr(check_flag, 1u);
-            reinterpret_cast<uint8_t *>(table)[idx] = (uint8_t)(((uint32_t)dc & 0xFu) | (((uint32_t)ds & 0xFu) << 4));
+            const int2 p = tab_predict_nib(rec, u & ((1u << d) - 1u), d);
+            const uint32_t nc = (uint32_t)(c - p.x), ns = (uint32_t)(s - p.y);        // the biased fields
+            if (check_flag && (nc | ns) > 15u) atomicOr(check_flag, 1u);
+            reinterpret_cast<uint8_t *>(table)[idx] = (uint8_t)((nc & 0xFu) | ((ns & 0xFu) << 4));
         } else {
+            const int2 p = tab_predict(rec, u & ((1u << d) - 1u), d);
+            const int32_t dc = c - p.x, ds = s - p.y;
             if (check_flag && !(fits_bits(dc, 8) && fits_bits(ds, 8))) atomicOr(check_flag, 1u);
             reinterpret_cast<uint16_t *>(table)[idx] = (uint16_t)(((uint32_t)dc & 0xFFu) | (((uint32_t)ds & 0xFFu) << 8));
         }

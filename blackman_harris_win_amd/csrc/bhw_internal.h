@@ -97,7 +97,7 @@ int bhwk_table_combine_fold(const BhwLaunch &l, const BhwCordicCfg &c, const Bhw
 // whole period, 15-block super-tiles over the residue-split table (z_shr == 0 only)
 int bhwk_table_combine_tile(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out);
 bool bhwk_tile_applicable(const BhwCordicCfg &c, const BhwWinCfg &w);
-void bhwk_describe_table(const BhwCordicCfg &c, const BhwWinCfg &w, bool tiled, char *build, char *combine, size_t len);
+void bhwk_describe_table(const BhwCordicCfg &c, const BhwWinCfg &w, bool tiled, bool images, char *build, char *combine, size_t len);
 // tiles [tile0, tile0 + tile_count) of the tile plan only (tile_count 0: the whole ring)
 int bhwk_table_combine_tile_range(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const int32_t *d_table, int32_t *d_out,
                                   uint32_t tile0, uint32_t tile_count, uint32_t img_mask = 0xFFu, uint32_t n0mod = 0u);

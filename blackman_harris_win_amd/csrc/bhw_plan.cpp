@@ -430,6 +430,16 @@ bool bhwp_tile_fast(const BhwCordicCfg &c, const BhwWinCfg &w, int nb)
     return fast;
 }
 
+// Measured per instance (profiles/r05_kernel_stats_all_legs.csv against round 4's): plain nibbles 60.6 us (HLS rule, 61.3 before) and
+// 61.3 us (VHDL rule at 32 bits, 71.7 before); nibble + escapes 69.7 us with the VHDL rule at 32 bits (74.2 before) but 68.9 us with
+// the HLS rule (64.6 in k_table_combine_tile, whose run of the escape test costs less there): those stay where they were.
+bool bhwk_tile9_applicable(const BhwCordicCfg &c, const BhwWinCfg &w, int nb, bool fast, bool masked)
+{
+    const int fmt = fmt_of(c.tab_dlog);
+    if (!(nb == 15 && fast && !masked && fmt_cell_log(c.tab_dlog) == kTile9CellLog && c.z_shr == 0)) return false;
+    return fmt == 3 || (fmt == 5 && w.combine != BHW_COMBINE_HLS && c.dat_width == 32u);
+}
+
 // A contiguous index range that is a whole number of eighths of the window (and less than all of it) can be produced by the
 // tile kernel as a subset of its eight images: `*img_mask` = the images, `*n0mod` = n0 mod N (see BhwTilePlan).
 bool bhwk_tile_images_applicable(const BhwCordicCfg &c, const BhwWinCfg &w, uint64_t n0, uint64_t count, uint32_t *img_mask, uint32_t *n0mod)
@@ -590,7 +600,7 @@ bool bhwp_part_fused(const bhw_params *p, const BhwCordicCfg &c, const BhwFoldRu
 
 // Kernel names of the table strategy's two passes for a resolved configuration (bhw_describe_plan: profilers, bench labels).
 // Mirrors the dispatch in bhwk_table_build / bhwk_table_combine_tile_range / bhwk_table_combine_fold.
-void bhwk_describe_table(const BhwCordicCfg &c_in, const BhwWinCfg &w, bool tiled, char *build, char *combine, size_t len)
+void bhwk_describe_table(const BhwCordicCfg &c_in, const BhwWinCfg &w, bool tiled, bool images, char *build, char *combine, size_t len)
 {
     const BhwCordicCfg c = table_layout(c_in);
     const uint32_t entries = 1u << (c.phi_width - 2 - c.z_shr);
@@ -604,7 +614,9 @@ void bhwk_describe_table(const BhwCordicCfg &c_in, const BhwWinCfg &w, bool tile
     const int mode = mode_of(c, w);
     if (tiled) {
         const int nb3 = (c.z_shr == 0 && w.n_terms > 3) ? 3 : 1, nb5 = (c.z_shr == 0 && w.n_terms > 5) ? 5 : 1;
-        snprintf(combine, len, "k_table_combine_tile<%d,%d,%d>", nb3 * nb5, mode, fmt);
+        // (`images`: a subset of the eight images, which k_table_combine_tile's MASKED instances produce)
+        if (bhwk_tile9_applicable(c, w, nb3 * nb5, bhwp_tile_fast(c, w, nb3 * nb5), images)) snprintf(combine, len, "k_tile9<%d,%d>", mode, fmt);
+        else snprintf(combine, len, "k_table_combine_tile<%d,%d,%d>", nb3 * nb5, mode, fmt);
     } else if (c.tab_dlog == 0 && !c.tab_split) snprintf(combine, len, "k_table_combine_fold_t<%u,%d>", w.n_terms, mode);
     else snprintf(combine, len, "k_table_combine_fold");
 }
@@ -775,7 +787,7 @@ int bhw_describe_plan(const bhw_params *p, uint64_t n0, uint64_t count, const bh
         break;
     }
     char build[64], combine[96];
-    bhwk_describe_table(c, w, t.tiled, build, combine, sizeof build);
+    bhwk_describe_table(c, w, t.tiled, t.images, build, combine, sizeof build);
     if (period && c.tab_dlog == 0 && bhwk_runlength_applicable(c, w, nullptr))     // generate_impl's period(): dropped phase bits
         snprintf(combine, sizeof combine, "k_runlength_window<%u,%d,%s> (16-byte aligned output; else k_table_combine_fold_t)", p->n_terms,
                  mode_of(c, w), c.dat_width <= 16 ? "true" : "false");

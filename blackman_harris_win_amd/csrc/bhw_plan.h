@@ -66,6 +66,11 @@ struct BhwTilePlan {
 void bhwp_tile_plan(const BhwCordicCfg &c, const BhwWinCfg &w, BhwTilePlan &tp, int &nb, uint32_t &lanes);
 // one-instruction products in the 15-run tile kernel (tile_harmonic FAST) for these weights and this cosine-sum rule
 bool bhwp_tile_fast(const BhwCordicCfg &c, const BhwWinCfg &w, int nb);
+// k_tile9 (bhw_tile9.hip), the 15-run tile kernel compiled for one-byte tables with cells of 2^9 entries: applies to whole 15-run
+// tiles with one-instruction products and all eight images, where it measured faster (everything else: k_table_combine_tile)
+constexpr uint32_t kTile9CellLog = 9;
+bool bhwk_tile9_applicable(const BhwCordicCfg &c, const BhwWinCfg &w, int nb, bool fast, bool masked);
+int bhwk_tile9(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, const BhwTilePlan &tp, uint32_t tile_count, const int32_t *d_table, int32_t *d_out);
 
 // Form of the fused kernel for a launch of `total` ring lanes: which kernel bhwk_fold_direct starts (and bhw_describe_plan names).
 enum { BHWP_FOLD_SEQUENTIAL = 0, BHWP_FOLD_LOCKSTEP = 1, BHWP_FOLD_NARROW = 2, BHWP_FOLD_SPLIT = 3 };

@@ -95,7 +95,8 @@ static void sweep_config(bhw_params &p, int parts)
                     cf.tab_dlog = cand[i];
                     REQUIRE(fmt_of(cand[i]) == 1 || bhwk_build_mirror_applies(table_layout(cf), (uint32_t)E), "format %u proposed without a build kernel", cand[i]);
                     char b1[64], b2[64];
-                    bhwk_describe_table(cf, w, tiled != 0, b1, b2, sizeof b1);
+                    bhwk_describe_table(cf, w, tiled != 0, false, b1, b2, sizeof b1);
+                    bhwk_describe_table(cf, w, tiled != 0, true, b1, b2, sizeof b1);
                 }
             }
             for (int state = 0; state < 3; ++state) {             // every packed format unknown / exact / overflowing

@@ -155,14 +155,14 @@ def test_headline_kernels_have_no_scratch():
         _build.build_library(force=True)
     with open(_build.RESOURCES) as f:
         res = json.load(f)
-    headline = ["k_table_build_mirror<32, 3, 1024>", "k_table_build_mirror<32, 2, 1024>", "k_table_build_mirror<31, 3, 1024>", "k_table_build_mirror<32, 3, 256>", "k_table_combine_tile<15, 2, 3, true, false>", "k_table_combine_tile<15, 0, 3, true, false>",
+    headline = ["k_tile9<0, 3, false, false>", "k_tile9<2, 3, false, true>", "k_tile9<2, 5, false, true>", "k_tile9<0, 3, true, false>", "k_table_combine_tile<15, 1, 5, true, false>", "k_table_build_mirror<32, 3, 1024>", "k_table_build_mirror<32, 2, 1024>", "k_table_build_mirror<31, 3, 1024>", "k_table_build_mirror<32, 3, 256>", "k_table_combine_tile<15, 2, 3, true, false>", "k_table_combine_tile<15, 0, 3, true, false>",
                 "k_table_combine_tile<15, 0, 2, true, false>", "k_table_combine_tile<15, 1, 2, true, false>", "k_table_combine_tile<15, 0, 2, false, false>",
                 "k_fold_direct<7, 0, 0>", "k_fold_direct<4, 0, 2>", "k_fold_direct<4, 0, 1>", "k_fold_split<4, 0>", "k_runlength_window<7, 1, true>"]
     for name in headline:
         assert name in res, name
     for name, r in res.items():                                      # no kernel of the library uses scratch
         assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0, (name, r)
-    for name in ("k_table_combine_tile<15, 0, 3, true, false>", "k_table_combine_tile<15, 0, 2, true, false>"):
+    for name in ("k_tile9<0, 3, false, false>", "k_tile9<2, 3, false, true>", "k_tile9<2, 5, false, true>", "k_tile9<0, 3, true, false>", "k_table_combine_tile<15, 1, 5, true, false>", "k_table_combine_tile<15, 0, 3, true, false>", "k_table_combine_tile<15, 0, 2, true, false>"):
         assert res[name]["VGPRs"] <= 64 and res[name]["LDS Size"] <= 80 * 1024, (name, res[name])   # two 960-thread workgroups per CU
     for name in ("k_table_build_mirror<32, 3, 1024>", "k_table_build_mirror<32, 2, 1024>"):
         assert res[name]["VGPRs"] <= 64 and res[name]["LDS Size"] <= 80 * 1024, (name, res[name])   # two 1 024-thread workgroups per CU
@@ -198,8 +198,12 @@ def test_describe_plan_names_the_run_length_kernel():
     assert "k_runlength_window<7,1,true>" in B.describe_plan(p, 0, 1 << 26)
     p = B.make_params(4, 24, 18, model=B.MODEL_VHDL, combine=B.COMBINE_VHDL)
     assert "k_runlength_window<4,2,false>" in B.describe_plan(p, 0, 1 << 24)
-    p = B.make_params(7, 26, 32)                                  # no dropped bits: the tile kernel
-    assert "k_table_combine_tile<15,0," in B.describe_plan(p, 0, 1 << 26)
+    p = B.make_params(7, 26, 32)                                  # no dropped bits: the tile kernel (cells of 2^9 entries: its k_tile9 form)
+    assert "k_tile9<0," in B.describe_plan(p, 0, 1 << 26)
+    p = B.make_params(7, 24, 32)                                  # ... cells of 2^7 entries: the general tile kernel
+    assert "k_table_combine_tile<15,0," in B.describe_plan(p, 0, 1 << 24)
+    p = B.make_params(7, 26, 32)
+    assert "k_table_combine_tile<15,0," in B.describe_plan(p, 1 << 25, 1 << 25)      # half a window: an image subset
     # AUTO keeps such configurations on the table strategy once they are long enough for the run-length kernel
     p = B.make_params(4, 22, 8, model=B.MODEL_CPP)
     assert B.describe_plan(p, 0, 1 << 22).startswith("table")
