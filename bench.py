@@ -95,13 +95,32 @@ def cpu_baseline(target_seconds=12.0, max_threads=16):
 
 
 def sources_sha16():
-    """sha256 prefix of the kernel + ABI sources: ties a committed PMC summary to the code it was measured on."""
+    """sha256 prefix of EVERY source file that reaches libbhw.so (blackman_harris_win_amd/_build.py::library_sources: the kernel units,
+    the shared headers incl. bhw_tables.inc, the planner, the API layer, the Taylor ROM generator, include/bhw.h): ties a committed PMC
+    summary to the code it was measured on -- a change in any of them marks the citation stale."""
+    from blackman_harris_win_amd import _build
     h = hashlib.sha256()
-    for f in ("bhw_device.h", "bhw_build.hip", "bhw_combine.hip", "bhw_direct.hip", "bhw_fused.hip", "bhw_taylor.hip", "bhw_api.cpp", "bhw_plan.cpp",
-              "bhw_plan.h", "bhw_internal.h"):
-        with open(os.path.join(ROOT, "blackman_harris_win_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
+    for path in sorted(_build.library_sources()):
+        with open(path, "rb") as fh:
+            h.update(os.path.basename(path).encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
+
+
+def read_sclk(index=0):
+    """Current shader clock of GPU `index` in MHz from sysfs (pp_dpm_sclk: the level marked '*'), or None where the file is not
+    readable: clock evidence that does not depend on the driver's coarse gpu_busy sampling."""
+    import glob
+    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+    if not cards:
+        return None
+    try:
+        with open(cards[min(index, len(cards) - 1)]) as f:
+            for line in f:
+                if line.rstrip().endswith("*"):
+                    return int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+    except Exception:
+        return None
+    return None
 
 
 def pmc_traffic():
@@ -182,9 +201,15 @@ def launch_check(args, rank, world):
     own_ms = 0.002 * (rank + 1) * 1e3                       # this rank's own step time (stands in for the device time per step)
     del t_own
     group = group_record(dist if world > 1 else None, torch, "cpu", world, "gloo", own_ms)
+    strong_rec = None
+    if world > 1 and args.scaling == "weak":                    # like the GPU run: a weak multi-rank record also times the strong reading
+        s_el = timed_steps(lambda: time.sleep(0.002 * (rank + 1) / world), args.steps, args.warmup, dist.barrier, lambda: None, allreduce_max)
+        strong_rec = {"value": COUNT * args.steps / s_el / 1e9, "unit": "Gsamples/s", "ms_per_step": s_el / args.steps * 1e3,
+                      "steps": args.steps, "parity_spot_check": None, "launch_check": True}
     if rank == 0:
         print(json.dumps(dict({"launch_check": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": args.scaling,
-                               "ms_per_step": elapsed / args.steps * 1e3, "shard_of_last_rank": list(shard_for(world - 1))}, **group)), flush=True)
+                               "ms_per_step": elapsed / args.steps * 1e3, "shard_of_last_rank": list(shard_for(world - 1)),
+                               "strong": strong_rec}, **group)), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -214,6 +239,51 @@ def device_times(step, steps, torch):
     evs[steps].record()
     torch.cuda.synchronize()
     return [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+
+
+def golden_parity_owned(torch, out, segments, dev):
+    """Every committed golden sample of the C3 window that lies inside `segments` (this rank's ownership) matches: 0.0 yes, 1.0 no,
+    2.0 the fixture is missing.  (A float so that the ranks can max-reduce it.)"""
+    step_s = (1 << 23) // 1024
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
+            g = json.load(f)["entries"]["C3_bh7_26_32"]
+        owned = torch.zeros(COUNT, dtype=torch.bool, device=dev)
+        for s0, c in segments:
+            owned[s0:s0 + c] = True
+        bad = 0.0
+        for sh, e in enumerate(g["shards"]):
+            idx = (sh << 23) + step_s * torch.arange(1024, device=dev)
+            want = torch.tensor(e["strided_1024"], dtype=torch.int32, device=dev)
+            m = owned[idx]
+            if not bool((out[idx][m] == want[m]).all()):
+                bad = 1.0
+        return bad
+    except Exception:
+        return 2.0
+
+
+def strong_leg(torch, bhw, B, params, rank, world, dev, algo, steps, warmup, barrier, allreduce_max):
+    """BASELINE configs[4] as SURVEY 8(d) defines it -- ONE 2^26-point window over the ranks -- timed with the same protocol as the
+    headline, so that a multi-rank record of the default (weak) command carries both readings of "8 GPUs": `strong` = interleaved
+    ownership parts of one window (bhw_generate_part_device, no collective).  Returns the dict rank 0 prints as rec["strong"]."""
+    out = torch.empty(COUNT, dtype=torch.int32, device=dev)
+    ws_bytes = B.lib().bhw_workspace_bytes(ctypes.byref(params), 0, COUNT, B.ALGO_TABLE)
+    workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    segments = B.part_segments(params, rank, world)
+
+    def step():
+        bhw.generate_part(params, rank, world, out, algo=algo, workspace=workspace)
+
+    step()
+    torch.cuda.synchronize()
+    elapsed = timed_steps(step, steps, warmup, barrier, torch.cuda.synchronize, allreduce_max)
+    worst = allreduce_max(golden_parity_owned(torch, out, segments, dev))
+    return {"value": COUNT * steps / elapsed / 1e9, "unit": "Gsamples/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+            "parity_spot_check": None if worst == 2.0 else worst == 0.0,
+            "workload": "ONE BH-7 2^26 / 32-bit window over the %d ranks: interleaved ownership parts, no collective (SURVEY 8(d) C5)" % world,
+            "coefficients_of_rank0": sum(c for _, c in segments),
+            "note": "same timing protocol as the headline (barrier + synchronize around K steps, max over ranks); value = 2^26 x K / time"}
 
 
 def extra_legs(torch, bhw, B, out, steps):
@@ -303,6 +373,25 @@ def extra_legs(torch, bhw, B, out, steps):
         del bufs
     except Exception as e:
         legs["C2_bh4_2^20_24bit_graph_4streams"] = {"error": repr(e)}
+    # the streaming-frame size of configs[3] with the headline's window type: BH-7, N = 2^16, 32-bit, 20 windows per graph replay
+    p7s = bhw.make_params(WIN, 16, DAT_WIDTH)
+    bhw.prepare(p7s)
+    o7s = out[:1 << 16]
+    plan7s = B.describe_plan(p7s, 0, 1 << 16, B.ALGO_AUTO)
+    try:
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            bhw.generate(p7s, 0, 1 << 16, out=o7s)
+            st.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                for _ in range(20):
+                    bhw.generate(p7s, 0, 1 << 16, out=o7s)
+            leg = measure(g.replay, 20 << 16, plan7s, note="20 windows per HIP-graph replay; ms = per window", reps=50)
+        leg["ms"] /= 20.0
+        legs["bh7_2^16_32bit_graph"] = leg
+    except Exception as e:
+        legs["bh7_2^16_32bit_graph"] = {"error": repr(e)}
     # BASELINE configs[3]: 1024 frames x BH-4 N = 2^16, 24-bit (one period computed, then store-only replication)
     p4 = bhw.make_params(4, 16, 24)
     o4 = out.view(1024, 1 << 16)
@@ -320,6 +409,44 @@ def extra_legs(torch, bhw, B, out, steps):
     # ... and with the VHDL CORDIC as well (model C end to end)
     pvv = bhw.make_params(WIN, PHI_WIDTH, DAT_WIDTH, model=B.MODEL_VHDL, combine=B.COMBINE_VHDL)
     legs["C3_vhdl_cordic_and_sum"] = measure(lambda: bhw.generate(pvv, 0, n26, out=out), n26, lambda: B.describe_plan(pvv, 0, n26, B.ALGO_AUTO))
+    # Pipelined THROUGHPUT of the headline window -- never the headline: successive windows alternate between two streams (own output
+    # buffer and own library scratch each), so the build pass of window i + 1 (vector-issue bound, writes 22 MB) can run beside the
+    # combine pass of window i (memory bound).  Every window still builds its own table.
+    try:
+        p3s = bhw.make_params(WIN, PHI_WIDTH, DAT_WIDTH)
+        out_b = torch.empty_like(out)
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        for s_ in (sa, sb):
+            with torch.cuda.stream(s_):
+                bhw.prepare(p3s)
+        torch.cuda.synchronize()
+        pairs = 25
+
+        def two_streams():
+            fork = torch.cuda.Event()
+            fork.record()
+            sa.wait_event(fork)
+            sb.wait_event(fork)
+            for _ in range(pairs):
+                with torch.cuda.stream(sa):
+                    bhw.generate(p3s, 0, n26, out=out)
+                with torch.cuda.stream(sb):
+                    bhw.generate(p3s, 0, n26, out=out_b)
+            cur = torch.cuda.current_stream()
+            for s_ in (sa, sb):
+                join = torch.cuda.Event()
+                join.record(s_)
+                cur.wait_event(join)
+
+        leg = measure(two_streams, 2 * pairs * n26, lambda: B.describe_plan(p3s, 0, n26, B.ALGO_AUTO) + " -- windows alternating over two streams",
+                      note="throughput of back-to-back windows on two streams (build of one beside the combine of the other); ms = per window; "
+                           "the latency of ONE window is the headline", reps=4)
+        leg["ms"] /= 2 * pairs
+        leg["same_as_headline"] = bool(torch.equal(out, out_b))
+        legs["C3_two_streams"] = leg
+        del out_b
+    except Exception as e:
+        legs["C3_two_streams"] = {"error": repr(e)}
     # fused apply y = (x * w) >> 31: reads x, writes y, no coefficient vector in HBM
     x = torch.randint(-(1 << 31), (1 << 31) - 1, (n26,), dtype=torch.int32, device=out.device)
     p3 = bhw.make_params(WIN, PHI_WIDTH, DAT_WIDTH)
@@ -449,6 +576,7 @@ def main():
     # the same K steps straight after W warm-up steps, BEFORE the ramp: what a cold device gives (DVFS), printed beside the
     # ramped figure so the effect of the ramp is in the record and not in prose
     no_ramp_elapsed = timed_steps(step, args.steps, args.warmup, barrier, torch.cuda.synchronize, allreduce_max)
+    sclk_cold = read_sclk(local_rank)
     t_ramp = time.perf_counter()
     ramp_steps = 0
     while time.perf_counter() - t_ramp < args.ramp_seconds:
@@ -460,7 +588,9 @@ def main():
         step()
     ev0.record()                                   # torch creates the HIP event handle at the first record(): not inside the timed region
     ev1.record()                                   # (two hipEventCreate calls cost ~25 us there -- 1 % of a 20-step run)
+    sclk_before = read_sclk(local_rank)
     elapsed = timed_steps(step_with_events, args.steps, 0, barrier, torch.cuda.synchronize, allreduce_max)
+    sclk_after = read_sclk(local_rank)
     own_dev_ms = ev0.elapsed_time(ev1) / args.steps
     dev_ms = allreduce_max(own_dev_ms)
     group = group_record(dist, torch, dev if args.backend == "nccl" else "cpu", world, args.backend, own_dev_ms)
@@ -500,22 +630,7 @@ def main():
     if strong and world > 1:
         # this rank holds only its segments: every golden sample inside them must match.  Every rank reaches the collective
         # whatever happened to it (a mismatch or a missing fixture on one rank must not leave the others waiting in it).
-        bad = 0.0
-        try:
-            with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
-                g = json.load(f)["entries"]["C3_bh7_26_32"]
-            owned = torch.zeros(COUNT, dtype=torch.bool, device=dev)
-            for s0, c in segments:
-                owned[s0:s0 + c] = True
-            for sh, e in enumerate(g["shards"]):
-                idx = (sh << 23) + step_s * torch.arange(1024, device=dev)
-                want = torch.tensor(e["strided_1024"], dtype=torch.int32, device=dev)
-                m = owned[idx]
-                if not bool((out[idx][m] == want[m]).all()):
-                    bad = 1.0
-        except Exception:
-            bad = 2.0
-        worst = allreduce_max(bad)
+        worst = allreduce_max(golden_parity_owned(torch, out, segments, dev))
         parity = None if worst == 2.0 else worst == 0.0
     try:
         with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
@@ -553,6 +668,15 @@ def main():
                    "note": "same window, CORDIC bit-model of cpp/cordic_sincos.cpp (BHW_MODEL_CPP) in the HLS cosine-sum; device time"}
         step()                                                  # leave the headline window in `out`
 
+    # what the library itself holds for this stream (the cpp leg and the extra legs run on it; the headline passes its own workspace)
+    try:
+        Lq = B.lib()
+        Lq.bhw_dbg_library_scratch_bytes.restype = ctypes.c_uint64
+        Lq.bhw_dbg_library_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_void_p]
+        lib_scratch = int(Lq.bhw_dbg_library_scratch_bytes(local_rank, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    except Exception:
+        lib_scratch = None
+
     legs = None
     if not strong and rank == 0 and world == 1 and not args.no_extra_legs:
         legs = extra_legs(torch, bhw, B, out, args.steps)
@@ -563,7 +687,7 @@ def main():
         # counted bytes beside every leg (profiles/pmc_legs_latest.json, hash-tied to the kernel sources)
         cited, cited_src = pmc_legs_traffic()
         alias = {"C2_bh4_2^20_24bit_per_call": "C2_bh4_2^20_24bit", "C2_bh4_2^20_24bit_graph": "C2_bh4_2^20_24bit",
-                 "C2_bh4_2^20_24bit_graph_4streams": "C2_bh4_2^20_24bit"}
+                 "C2_bh4_2^20_24bit_graph_4streams": "C2_bh4_2^20_24bit", "C3_two_streams": "headline_C3"}
         for name, leg in legs.items():
             c = cited.get(alias.get(name, name))
             if isinstance(leg, dict) and "ms" in leg:
@@ -573,6 +697,12 @@ def main():
                     leg["counted_write_GB/s"] = c["write_bytes_per_call"] / (leg["ms"] * 1e-3) / 1e9
         legs["_traffic_source"] = cited_src
         step()
+
+    # A multi-rank record of the default (weak) command also carries the strong reading of configs[4] -- one window over the ranks --
+    # so that one SCALE record tells the whole story: weak scales trivially, strong is bounded by the table each part rebuilds
+    strong_rec = None
+    if world > 1 and not strong:
+        strong_rec = strong_leg(torch, bhw, B, params, rank, world, dev, algo, args.steps, args.warmup, barrier, allreduce_max)
 
     total = units_per_step * args.steps
     value = total / elapsed / 1e9
@@ -604,6 +734,10 @@ def main():
                              "note": "the same W warm-up + K timed steps run BEFORE the ramp (cold clocks); `value` above is after it"}},
         "ranks_seen": group["ranks_seen"], "device_ms_per_step_by_rank": group["device_ms_per_step_by_rank"], "backend": group["backend"],
         "scratch_bytes": int(workspace.numel()) if workspace is not None else 0,
+        "library_scratch_bytes": lib_scratch,
+        "sclk_mhz": {"before_timed_region": sclk_before, "after_timed_region": sclk_after, "after_no_ramp_leg": sclk_cold,
+                     "source": "sysfs pp_dpm_sclk of this rank's GPU (None: not readable on this box)"},
+        "strong": strong_rec,
         "parity_spot_check": parity,
         "cpp_model": cpp_leg,
         "extra_legs": legs,

@@ -68,6 +68,8 @@ struct Slot {
     std::mutex mu;
     void *buf = nullptr;
     uint64_t bytes = 0;
+    bool oversized = false;   // sized while some packed-format verdict of the configuration was still open (the maximum over
+                              // every candidate up to plain): re-sized once the verdicts are known, see acquire_scratch
 };
 struct DeviceScratch {
     std::map<void *, std::shared_ptr<Slot>> bufs;            // stream -> slot
@@ -97,6 +99,23 @@ int ensure_slot_bytes(Slot &slot, void *stream, uint64_t bytes)
         slot.buf = nullptr;
         slot.bytes = 0;
     }
+    void *b = nullptr;
+    const hipError_t e = hipMalloc(&b, bytes);
+    if (e != hipSuccess) return fail_hip(e, "hipMalloc(scratch)");
+    slot.buf = b;
+    slot.bytes = bytes;
+    return BHW_OK;
+}
+
+// slot.mu is held by the caller.  Gives back what a slot holds beyond `bytes` (never inside a capture: it synchronises).
+int shrink_slot_to(Slot &slot, void *stream, uint64_t bytes)
+{
+    if (slot.bytes <= bytes || stream_is_capturing(stream)) return BHW_OK;
+    (void)hipStreamSynchronize((hipStream_t)stream);          // earlier launches on this stream may still read it
+    (void)hipFree(slot.buf);
+    slot.buf = nullptr;
+    slot.bytes = 0;
+    if (!bytes) return BHW_OK;
     void *b = nullptr;
     const hipError_t e = hipMalloc(&b, bytes);
     if (e != hipSuccess) return fail_hip(e, "hipMalloc(scratch)");
@@ -224,7 +243,11 @@ struct TableScratch {
     std::shared_ptr<Slot> slot;
     std::unique_lock<std::mutex> lock;
 };
-int acquire_scratch(const bhw_exec *ex, int device, void *stream, uint64_t need, TableScratch &t)
+// `open_verdicts`: `need` is the maximum over formats whose verdict is not known yet (the first call of a configuration without
+// bhw_prepare_device).  The slot remembers that, and the next call that finds the verdicts settled gives the excess back once
+// (128 MiB -> 16.5 MiB for a 2^26-point window at 32 bits); a slot is never re-sized downwards otherwise, so streams that alternate
+// between configurations of different sizes do not re-allocate per call.
+int acquire_scratch(const bhw_exec *ex, int device, void *stream, uint64_t need, bool open_verdicts, TableScratch &t)
 {
     if (ex && ex->workspace) {
         if (ex->workspace_bytes < need)
@@ -234,10 +257,30 @@ int acquire_scratch(const bhw_exec *ex, int device, void *stream, uint64_t need,
     }
     t.slot = slot_of(device, stream);
     t.lock = std::unique_lock<std::mutex>(t.slot->mu);
+    if (t.slot->oversized && !open_verdicts && t.slot->bytes > need) {
+        t.slot->oversized = false;
+        const int rs = shrink_slot_to(*t.slot, stream, need);
+        if (rs) return rs;
+    }
+    const bool grows = t.slot->bytes < need;
     const int rc = ensure_slot_bytes(*t.slot, stream, need);
     if (rc) return rc;
+    if (grows && open_verdicts) t.slot->oversized = true;
     t.ws = t.slot->buf;
     return BHW_OK;
+}
+
+// true while some packed format this call may try has no verdict yet (its scratch is then sized for every candidate)
+bool verdicts_open(const bhw_params *p, const BhwCordicCfg &c, bool tiled, uint32_t limit)
+{
+    uint32_t cand[kMaxFormats];
+    const int n = bhwp_table_format_candidates(c, tiled, limit, cand);
+    for (int i = 0; i < n; ++i) {
+        const int v = cand[i] ? bhwp_fmt_verdict(p, cand[i]) : (int)kFmtOk;
+        if (v == kFmtOk) return false;
+        if (v == kFmtUnknown) return true;
+    }
+    return false;
 }
 
 int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, uint64_t count, int32_t *d_out,
@@ -312,7 +355,8 @@ int generate_impl(const bhw_params *p, int device, void *stream, uint64_t n0, ui
     // the plain 8 bytes per entry.  The scratch is sized for the format(s) this call may use.
     const uint32_t limit = bhwp_exec_table_format(ex);
     TableScratch scratch;
-    rc = acquire_scratch(ex, device, stream, bhwp_table_scratch_bytes(p, c, tiled, limit, stream_is_capturing(stream)), scratch);
+    const bool capturing = stream_is_capturing(stream);
+    rc = acquire_scratch(ex, device, stream, bhwp_table_scratch_bytes(p, c, tiled, limit, capturing), !capturing && verdicts_open(p, c, tiled, limit), scratch);
     if (rc) return rc;
     void *ws = scratch.ws;
     rc = build_table(p, l, c, tiled, limit, ws);
@@ -621,7 +665,8 @@ int bhw_generate_part_device(const bhw_params *p, int device, void *hip_stream, 
     c.tab_split = c.z_shr == 0 ? 1u : 0u;
     const uint32_t limit = bhwp_exec_table_format(ex);
     TableScratch scratch;
-    rc = acquire_scratch(ex, device, hip_stream, bhwp_table_scratch_bytes(p, c, true, limit, stream_is_capturing(hip_stream)), scratch);
+    const bool capturing = stream_is_capturing(hip_stream);
+    rc = acquire_scratch(ex, device, hip_stream, bhwp_table_scratch_bytes(p, c, true, limit, capturing), !capturing && verdicts_open(p, c, true, limit), scratch);
     if (rc) return rc;
     void *ws = scratch.ws;
     rc = build_table(p, l, c, true, limit, ws);
@@ -710,23 +755,58 @@ int bhw_prepare_device(const bhw_params *p, int device, void *hip_stream)
     const bool tile = bhwk_tile_applicable(c, w);
     const uint64_t plain = bhwp_table_layout(bhwp_table_entries(c), 0).bytes;
     uint64_t need = plain <= (64ull << 20) || !tile ? plain : 0;
+    const uint32_t limits[] = {BHW_TABLE_BEST, BHW_TABLE_NIBBLE_ESC, BHW_TABLE_RESIDUAL, BHW_TABLE_DELTA16};
     if (tile) {
         c.tab_split = c.z_shr == 0 ? 1u : 0u;
-        const uint64_t first = bhwp_table_scratch_bytes(p, c, true, BHW_TABLE_BEST, false);   // while formats are unverified: the widest that may be tried
-        if (first > need) need = first;
+        for (uint32_t limit : limits) {
+            const uint64_t first = bhwp_table_scratch_bytes(p, c, true, limit, false);   // while formats are unverified: the widest that may be tried
+            if ((limit == BHW_TABLE_BEST || verdicts_open(p, c, true, limit)) && first > need) need = first;
+        }
     }
     auto slot = slot_of(device, hip_stream);
     std::unique_lock<std::mutex> lk(slot->mu);
     rc = ensure_slot_bytes(*slot, hip_stream, need);
     if (rc) return rc;
-    // settle the packed-format verdicts of this configuration (build_table reads the check word back when one is open)
+    // Settle the packed-format verdict of EVERY format a later call may name (build_table reads the check word back when one is
+    // open): the chain table_format BEST walks, and each explicit limit -- a captured call with an explicit bhw_exec.table_format
+    // must not meet an open verdict (it would fall back to the plain table, which the scratch below no longer holds).
     if (tile) {
         BhwLaunch l{device, hip_stream};
-        rc = build_table(p, l, c, true, BHW_TABLE_BEST, slot->buf);
+        for (uint32_t limit : limits) {
+            if (limit != BHW_TABLE_BEST && !verdicts_open(p, c, true, limit)) continue;
+            rc = build_table(p, l, c, true, limit, slot->buf);
+            if (rc) return rc;
+        }
+    }
+    hipError_t he = hipStreamSynchronize((hipStream_t)hip_stream);
+    if (he != hipSuccess) return fail_hip(he, "hipStreamSynchronize");
+    // ... and with the verdicts known the scratch is what table_format BEST needs from now on (16.5 MiB instead of 128 MiB for a
+    // 2^26-point window at 32 bits), plus the plain table of partial ranges where that was reserved above
+    if (tile) {
+        const uint64_t settled = bhwp_table_scratch_bytes(p, c, true, BHW_TABLE_BEST, false);
+        const uint64_t keep = plain <= (64ull << 20) ? (plain > settled ? plain : settled) : settled;
+        slot->oversized = false;
+        rc = shrink_slot_to(*slot, hip_stream, keep);
         if (rc) return rc;
     }
-    const hipError_t he = hipStreamSynchronize((hipStream_t)hip_stream);
-    return he == hipSuccess ? BHW_OK : fail_hip(he, "hipStreamSynchronize");
+    return BHW_OK;
+}
+
+// Bytes the library-owned scratch of (device, hip_stream) holds right now (0: none yet) -- what bench.py reports beside the size of
+// the workspace it passes itself.  Not part of the ABI in include/bhw.h.
+uint64_t bhw_dbg_library_scratch_bytes(int device, void *hip_stream)
+{
+    std::shared_ptr<Slot> sp;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_scratch.find(device);
+        if (it == g_scratch.end()) return 0;
+        auto jt = it->second.bufs.find(hip_stream);
+        if (jt == it->second.bufs.end()) return 0;
+        sp = jt->second;
+    }
+    std::lock_guard<std::mutex> lk(sp->mu);
+    return sp->bytes;
 }
 
 } // extern "C"

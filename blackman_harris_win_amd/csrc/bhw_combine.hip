@@ -220,8 +220,8 @@ extern "C" int bhw_dbg_combine_stamps(void *d_words)      // 8 x uint64 per work
 // and the last of the 5.7 rounds of 512 such workgroups ran a third empty.  0.1002 -> 0.0967 ms per window, combine pass 67.7 ->
 // 63.5 us (profiles/r04_ab_tile_wg.txt; one wave per workgroup ties: 0.0972).  The five workgroups of a tile are dealt to the same
 // XCD one after the other, so the sibling runs still meet in one L2.
-// (The one- and three-run tiles of windows of up to five terms keep 960-thread workgroups: 192 there measured a tie, 0.0821 / 0.0816 ms
-// for BH-4 2^26 at 24 bits.)
+// (The one- and three-run tiles of windows of up to five terms keep ONE 960-thread workgroup per tile -- kWgPerTile = kWgPerPart = 1
+// there: five 192-thread workgroups measured a tie, 0.0821 / 0.0816 ms for BH-4 2^26 at 24 bits, and were not adopted.)
 constexpr int kTileWg = kTileLanes;
 constexpr int tile_wg_of(int nb) { return nb >= 15 ? kTileWg : kTileThreads; }
 template <int NB, int MODE, int FMT, bool FAST = false, bool MASKED = false>
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(tile_wg_of(NB)) __attribute__((amdgpu_waves_per_eu(
     // 16-byte records of the residual format).
     constexpr int kWgThreads = tile_wg_of(NB);
     constexpr uint32_t kWgPerTile = kTileThreads / kWgThreads;      // workgroups per tile
-    constexpr uint32_t kWgPerPart = kLanes / kWgThreads;            // ... per part: 1 for the 192-lane parts of a 15-run tile, 5 for the 960-lane runs of the others
+    constexpr uint32_t kWgPerPart = kLanes / kWgThreads;            // ... per part: 1 either way -- a 15-run tile is five 192-thread workgroups of one part each, a one- or three-run tile ONE 960-thread workgroup that is its only part
     static_assert(kWgPerPart * kWgThreads == kLanes && kWgPerPart * kParts == kWgPerTile, "a workgroup lies inside one part");
     uint32_t tile_of_block = blockIdx.x / kWgPerTile, part_of_block = blockIdx.x % kWgPerTile;
     {

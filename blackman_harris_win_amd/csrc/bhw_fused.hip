@@ -7,14 +7,17 @@
 
 namespace {
 
-// Output stage of the fused kernels: stores at agent scope (sc1), written through the L2 as they are produced.  The windows these
-// kernels take (up to 2^22 coefficients, 16 MB) fit the L2s, and with write-back stores the whole window stayed dirty there until
-// the end-of-kernel release wrote it back -- inside the gap before the next dependent launch: BH-4 2^20 / 24-bit 6.05 -> 5.64 us per
-// window in a 20-call graph, BH-4 2^22 15.3 -> 13.1 us, BH-3 2^22 / 20-bit 10.2 -> 8.1 us (profiles/r04_short_windows_store_scope.txt).
-__device__ __forceinline__ void emit_f(const BhwWinCfg &win, int32_t *__restrict__ out, uint64_t idx, int32_t w)
+// Output stage of the fused kernels.  `through`: stores at agent scope (sc1), written through the L2 as they are produced.  Windows of
+// up to 2^24 coefficients fit the L2s, and with write-back stores the whole window stayed dirty there until the end-of-kernel
+// release wrote it back -- inside the gap before the next dependent launch: BH-4 2^20 / 24-bit 6.05 -> 5.64 us per window in a
+// 20-call graph, BH-4 2^22 15.3 -> 13.1 us, BH-3 2^22 / 20-bit 10.2 -> 8.1 us (profiles/r04_short_windows_store_scope.txt).  Longer
+// ones (explicit BHW_ALGO_FUSED up to phi_width 30, ownership parts of 2^26-point windows) keep write-back stores: at agent scope the
+// tile kernel's 268 MB took 91 instead of 67 us (profiles/r04_ab_store_scope.txt) -- the same rule as k_table_combine_tile / k_tile9.
+__device__ __forceinline__ void emit_f(const BhwWinCfg &win, int32_t *__restrict__ out, uint64_t idx, int32_t w, bool through)
 {
     if (win.apply_x) w = (int32_t)(((int64_t)__builtin_nontemporal_load(&win.apply_x[idx]) * (int64_t)w) >> win.apply_shift);
-    asm volatile("global_store_dword %0, %1, off sc1" :: "v"(out + idx), "v"(w) : "memory");
+    if (through) asm volatile("global_store_dword %0, %1, off sc1" :: "v"(out + idx), "v"(w) : "memory");   // (wave-uniform)
+    else out[idx] = w;
 }
 
 
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win, BhwFo
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) emit_f(win, out, (uint64_t)(r + (uint32_t)h * H) + (uint64_t)j * E, vout[h][j]);
+            for (int j = 0; j < 4; ++j) emit_f(win, out, (uint64_t)(r + (uint32_t)h * H) + (uint64_t)j * E, vout[h][j], plan.phi_width <= 24u);
         return;
     }
     // Batched identical frames (bhw_generate_batched_device: the coefficient stream is periodic, src/bh_win_7term.vhd:92-97): the
@@ -616,7 +619,7 @@ __global__ __launch_bounds__(256) void k_fold_split(BhwWinCfg win, BhwFoldPlan p
             int32_t v;
             if constexpr (MODE == 2) v = w32_final<BHW_COMBINE_VHDL>(acc[j], W, NTERMS);
             else v = (int32_t)((uint32_t)acc[j] << (32u - W)) >> (32u - W);
-            emit_f(win, out, (uint64_t)(r + (uint32_t)HH * H) + (uint64_t)j * E, v);
+            emit_f(win, out, (uint64_t)(r + (uint32_t)HH * H) + (uint64_t)j * E, v, plan.phi_width <= 24u);
         }
     };
     if (wave == 0u) combine(std::integral_constant<int, 0>{});

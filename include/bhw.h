@@ -163,7 +163,10 @@ uint64_t bhw_workspace_bytes(const bhw_params *p, uint64_t n0, uint64_t count, u
 /* The same for the call as `ex` describes it (algo, table_format), counting the table format(s) the call would use right now:
  * after bhw_prepare_device (or a first call) has settled the packed formats of the configuration this is the size of the one
  * format in use -- 16.5 MiB instead of 128 MiB for a 2^26-point window at 32 bits -- and it never grows afterwards.  A
- * workspace of at least this size is accepted by the call; the library-owned scratch of a stream is sized by the same rule. */
+ * workspace of at least this size is accepted by bhw_generate_device_ex / bhw_generate_part_device (bhw_apply_device takes no
+ * bhw_exec: it always uses the library-owned scratch).  The library-owned scratch of a stream is sized by the same rule:
+ * bhw_prepare_device leaves it at this size; a stream that was never prepared holds the 8-bytes-per-entry bound from its first
+ * call (which has to try the formats) until the next call of that configuration, which gives the excess back once. */
 uint64_t bhw_workspace_bytes_ex(const bhw_params *p, uint64_t n0, uint64_t count, const bhw_exec *ex);
 
 /* What bhw_generate_device_ex(p, ..., n0, count, ..., ex) would launch right now, as one line of text into buf (NUL-terminated,
@@ -177,8 +180,11 @@ int bhw_describe_plan(const bhw_params *p, uint64_t n0, uint64_t count, const bh
  * of the configuration, not of the weights.  Synchronous.  After it, bhw_generate_* / bhw_apply_* / bhw_sincos_* calls with
  * these widths on this stream neither allocate nor synchronise, so they can be captured into a HIP graph -- whole periods,
  * partial ranges and explicit bhw_exec.algo alike (the scratch is reserved also for configurations whose whole periods take the
- * table-free fused kernel).  One exception: a range WITHOUT a whole period of a window whose plain table exceeds 64 MiB
- * (phi_width >= 26 at z_shr = 0) grows the scratch on its first use; pass bhw_exec.workspace for such calls inside a capture.
+ * table-free fused kernel).  The verdict of every packed format is settled, so an explicit bhw_exec.table_format never meets
+ * an open one; the scratch is sized for table_format BEST (the narrowest exact format).  Two exceptions, both answered by
+ * passing bhw_exec.workspace (bhw_workspace_bytes_ex bytes) inside a capture: a range WITHOUT a whole period of a window whose
+ * plain table exceeds 64 MiB (phi_width >= 26 at z_shr = 0), and an explicit table_format wider than the one BEST resolves to --
+ * either would have to grow the library scratch, which a capturing stream refuses (BHW_ERR_HIP).
  * Without prepare the first call does the same work inline (one synchronisation); during stream capture an unprepared Taylor
  * call fails with BHW_ERR_HIP and an unprepared table call uses the plain table format. */
 int bhw_prepare_device(const bhw_params *p, int device, void *hip_stream);

@@ -110,6 +110,9 @@ def test_bench_launches_its_own_ranks():
     # the record checks itself: the process group saw both ranks, and every rank's own time is in it (rank r sleeps 2 (r + 1) ms)
     assert rec["ranks_seen"] == 2 and rec["backend"] == "gloo"
     assert rec["device_ms_per_step_by_rank"] == [2.0, 4.0]
+    # a weak multi-rank record also carries the strong reading of configs[4] (ONE window over the ranks), timed the same way
+    assert rec["scaling"] == "weak" and set(rec["strong"]) >= {"value", "ms_per_step", "parity_spot_check"}
+    assert rec["strong"]["ms_per_step"] >= 0.9 * 2.0 and rec["strong"]["value"] > 0      # rank 1 sleeps 4 ms / 2 ranks per step
 
 
 def test_bench_refuses_mismatched_world():
@@ -136,3 +139,21 @@ def test_bench_strong_scaling_two_ranks_share_one_gpu():
     assert rec["ranks_seen"] == 2 and rec["backend"] == "gloo" and len(rec["device_ms_per_step_by_rank"]) == 2
     assert max(rec["device_ms_per_step_by_rank"]) == pytest.approx(rec["roofline"]["device_ms_per_step"])
     assert rec["ramp"]["no_ramp"]["ms_per_step"] > 0
+    assert rec["strong"] is None                                 # (the strong run itself is the record)
+
+
+@pytest.mark.gpu
+def test_bench_weak_record_carries_the_strong_reading():
+    """bench.py --gpus 2 (default, weak) through its own launcher, both ranks on this box's one GPU over gloo: the one JSON line holds
+    the weak headline AND `strong` -- one window over the two ranks, parity checked on every rank's own segments."""
+    import json
+    import subprocess
+    env = dict(_bench_env(), BHW_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "5", "--warmup", "2",
+                        "--ramp-seconds", "0.2", "--no-cpp-leg"], capture_output=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    rec = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["parity_spot_check"] is True and rec["ranks_seen"] == 2
+    s = rec["strong"]
+    assert s["parity_spot_check"] is True and s["value"] > 0 and s["ms_per_step"] > 0 and s["steps"] == 5
+    assert "ONE BH-7 2^26" in s["workload"]

@@ -191,6 +191,65 @@ def test_library_scratch_is_sized_by_the_format_in_use(torch):
     assert ei.value.code == -4
 
 
+def test_library_scratch_gives_the_excess_back_once_the_formats_are_settled(torch):
+    """Round-4 advisor finding: the first call of a configuration has to size the stream's scratch for every format it may try (8 bytes
+    per entry: 128 MiB for the 2^26-point window at 32 bits) and the slot kept that size for good.  Now the next call of the
+    configuration re-sizes it to the format in use (16.5 MiB), bhw_prepare_device leaves it there directly, and every later call
+    produces the same window.  After prepare a captured call with an explicit, wider table_format is refused with a message that
+    names the remedy (the library scratch cannot grow inside a capture) and works with the caller's workspace."""
+    import blackman_harris_win_amd as bhw
+    L = _dbg()
+    L.bhw_dbg_library_scratch_bytes.restype = ctypes.c_uint64
+    L.bhw_dbg_library_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    p = B.make_params(7, 26, 32)
+    n = 1 << 26
+    d = ctypes.c_uint32()
+    assert L.bhw_dbg_table_format_info(ctypes.byref(p), ctypes.byref(d), None) == 0 and d.value == 9
+    ex = B.BhwExec()
+    ex.struct_size = ctypes.sizeof(B.BhwExec)
+    ex.algo = B.ALGO_TABLE
+    bound = B.lib().bhw_workspace_bytes(ctypes.byref(p), 0, n, B.ALGO_TABLE)
+    for k in (16 + 9, 48 + 9, 9, 6):
+        assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), k, 3) == 0              # forget what earlier tests settled
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        out = torch.zeros(n, dtype=torch.int32, device="cuda")
+        bhw.generate(p, 0, n, out=out)                                                   # unprepared: tries the formats
+        st.synchronize()
+        assert L.bhw_dbg_library_scratch_bytes(0, ctypes.c_void_p(st.cuda_stream)) == bound
+        first = out.clone()
+        tight = B.lib().bhw_workspace_bytes_ex(ctypes.byref(p), 0, n, ctypes.byref(ex))
+        assert tight < bound // 7
+        out.zero_()
+        bhw.generate(p, 0, n, out=out)                                                   # verdicts known: the excess goes back
+        st.synchronize()
+        assert L.bhw_dbg_library_scratch_bytes(0, ctypes.c_void_p(st.cuda_stream)) == tight
+        assert torch.equal(out, first)
+    st2 = torch.cuda.Stream()
+    with torch.cuda.stream(st2):
+        bhw.prepare(p)
+        assert L.bhw_dbg_library_scratch_bytes(0, ctypes.c_void_p(st2.cuda_stream)) == tight
+        for k in (16 + 9, 9, 6):
+            assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), k, 0) in (1, 2)      # every explicit choice has its verdict
+        out2 = torch.zeros(n, dtype=torch.int32, device="cuda")
+        st2.synchronize()
+        g_bad = torch.cuda.CUDAGraph()
+        with pytest.raises(B.BhwError) as ei:
+            with torch.cuda.graph(g_bad, stream=st2):
+                bhw.generate(p, 0, n, out=out2, algo=B.ALGO_TABLE, table_format=B.TABLE_RESIDUAL)
+        assert ei.value.code == -3 and "workspace" in ei.value.detail
+        del g_bad
+        ex.table_format = B.TABLE_RESIDUAL
+        ws = torch.empty(B.lib().bhw_workspace_bytes_ex(ctypes.byref(p), 0, n, ctypes.byref(ex)), dtype=torch.uint8, device="cuda")
+        assert tight < ws.numel() < bound
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st2):
+            bhw.generate(p, 0, n, out=out2, algo=B.ALGO_TABLE, table_format=B.TABLE_RESIDUAL, workspace=ws)
+        graph.replay()
+        st2.synchronize()
+        assert torch.equal(out2, first)
+
+
 def _dbg():
     L = B.lib()
     P = ctypes.POINTER(B.BhwParams)
