@@ -430,14 +430,21 @@ bool bhwp_tile_fast(const BhwCordicCfg &c, const BhwWinCfg &w, int nb)
     return fast;
 }
 
-// Measured per instance (profiles/r05_kernel_stats_all_legs.csv against round 4's): plain nibbles 60.6 us (HLS rule, 61.3 before) and
-// 61.3 us (VHDL rule at 32 bits, 71.7 before); nibble + escapes 69.7 us with the VHDL rule at 32 bits (74.2 before) but 68.9 us with
-// the HLS rule (64.6 in k_table_combine_tile, whose run of the escape test costs less there): those stay where they were.
+// Measured per instance (profiles/r05_kernel_stats_all_legs_tile9_everywhere.csv against round 4's): plain nibbles 60.6 us (HLS rule,
+// 61.3 before) and 61.3 us (VHDL rule at 32 bits, 71.7 before); nibble + escapes 69.7 us with the VHDL rule at 32 bits (74.2 before)
+// but 68.9 - 70.8 us with the HLS rule, against 64 - 67 in k_table_combine_tile: those stay where they were (-DBHW_T9_ALLFMT5 sends
+// them here for the A/B harness).  What those tables cost is not the escape test -- with the marker never looked for, or the very
+// code of the plain-nibble instance run over them, the pass stays 6 us slower than over an HLS-model table
+// (profiles/r05_ab_tile9_cpp_model_fmt5.txt, r05_ab_tile9_fmt5_code_vs_table.txt): unexplained, recorded as such.
 bool bhwk_tile9_applicable(const BhwCordicCfg &c, const BhwWinCfg &w, int nb, bool fast, bool masked)
 {
     const int fmt = fmt_of(c.tab_dlog);
     if (!(nb == 15 && fast && !masked && fmt_cell_log(c.tab_dlog) == kTile9CellLog && c.z_shr == 0)) return false;
+#ifdef BHW_T9_ALLFMT5
+    return fmt == 3 || fmt == 5;                                     // (development: every nibble + escapes instance, for the A/B harness)
+#else
     return fmt == 3 || (fmt == 5 && w.combine != BHW_COMBINE_HLS && c.dat_width == 32u);
+#endif
 }
 
 // A contiguous index range that is a whole number of eighths of the window (and less than all of it) can be produced by the

@@ -175,6 +175,15 @@ __device__ __forceinline__ void t9_products(const BhwCordicCfg &cfg, const T9Ctx
         sv[3] = rp(a2, cs.y);
         sv[1] = rp(na2, cs.y ^ flip);
         sv[2] = rp(na2, cs.x ^ flip);
+    } else if constexpr (MODE == 1) {
+        // HLS rule on the cpp model's one's-complement map (cpp/cordic_sincos.cpp:70-86): the candidates are a c, a ~s, a ~c, a s, and
+        // a ~v = a (-v - 1) = (-a) v + (-a) exactly -- ONE v_mad_i64_i32 (high word) instead of v_not + v_mul_hi_i32
+        const int32_t na = -aK;
+        auto cp = [](int32_t w, int32_t v) -> int32_t { return (int32_t)(((int64_t)w * (int64_t)v + (int64_t)w) >> 32); };
+        sv[0] = __mulhi(aK, cs.x);
+        sv[3] = __mulhi(aK, cs.y);
+        sv[1] = cp(na, cs.y);
+        sv[2] = cp(na, cs.x);
     } else tile_harmonic<K, MODE, 0, 0, true>(cfg, aK, cx.W, cs, 0u, sv);
 }
 
@@ -191,6 +200,49 @@ __device__ __forceinline__ void t9_sum(const BhwCordicCfg &cfg, const T9Ctx &cx,
     } else {
         t9_products<K, MODE, VHDL32>(cfg, cx, aK, cs[B][1], sv);
         t9_accumulate<K, 0, ring_qbase(K, 1), ring_qbits(K, 1), B * kT9SetsPerRun + t9_set(K, 1)>(cx.qm0, cx.qm1, sv, acc[B][1]);
+    }
+}
+
+// Nibble + escapes, cold path: harmonic K of this wave read at least one marked entry.  Every gather of the harmonic is formed
+// again from the table (record from the record array, the byte itself), once as the hot path saw it -- the marker's fields taken at
+// face value -- and once with the listed pair in the marked lanes (esc_fix_wave: scalar unit, no extra vector registers); the
+// difference of the two contributions goes into the sums.  Unmarked lanes add zero.  Quadrants per lane (theta >> lq: the
+// wave-uniform value of the hot path, which only runs where no harmonic crosses a quarter turn inside a run).
+template <int K, int MODE, bool VHDL32>
+__device__ __forceinline__ void t9_esc_repair(const BhwCordicCfg &cfg, const T9Ctx &cx, const uint32_t (&rr)[kT9Runs], const int32_t aK, int32_t (&acc)[kT9Runs][2][4])
+{
+    constexpr int NG = (K & 1) ? 2 : 1;
+    const uint32_t lq = cfg.phi_width - 2u;
+    // (unrolled: the sums are registers)
+#pragma unroll
+    for (int b = 0; b < kT9Runs; ++b) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const uint32_t th = (uint32_t)K * (rr[b] + (uint32_t)g * cx.H), u = th & cx.emask;
+            const uint32_t byte = ld_off<uint8_t>(cx.table, u);
+            const bool marked = (byte & 0xFu) == kEscMarker;
+            if (__builtin_amdgcn_ballot_w64(marked) == 0ull) continue;                 // wave-uniform
+            const int2 p = tab_predict_nib(ld_off<int4>(cfg.tab_coarse, (u >> kT9D) << 4), u & ((1u << kT9D) - 1u), kT9D), n = nib_fields(byte);
+            const int2 wrong = make_int2(p.x + n.x, p.y + n.y);
+            int2 right = wrong;
+            esc_fix_wave(cfg.tab_esc, cfg.esc_wg_log, lq, u, marked, right);
+            int32_t sw[4], sr[4], d[4];
+            t9_products<K, MODE, VHDL32>(cfg, cx, aK, wrong, sw);
+            t9_products<K, MODE, VHDL32>(cfg, cx, aK, right, sr);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[i] = (K & 1) ? sw[i] - sr[i] : sr[i] - sw[i];   // odd harmonics are subtracted
+            const uint32_t q = th >> lq;
+            auto pick = [&](uint32_t i) -> int32_t { i &= 3u; return i == 0u ? d[0] : i == 1u ? d[1] : i == 2u ? d[2] : d[3]; };
+            // image j sits K * j quadrants after image 0; even K: the h = 1 image K / 2 quadrants further on (t9_sum)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (NG == 2) acc[b][g][j] += pick(q + (uint32_t)(j * K));
+                else {
+                    acc[b][0][j] += pick(q + (uint32_t)(j * K));
+                    acc[b][1][j] += pick(q + (uint32_t)(j * K + K / 2));
+                }
+            }
+        }
     }
 }
 
@@ -240,17 +292,6 @@ __device__ __forceinline__ void t9_finish(const BhwCordicCfg &cfg, const T9Ctx &
     t9_run<K, MODE, FMT, 0>(cx, wbase, rr, e, cs, esc_min);
     t9_run<K, MODE, FMT, 1>(cx, wbase, rr, e, cs, esc_min);
     t9_run<K, MODE, FMT, 2>(cx, wbase, rr, e, cs, esc_min);
-    if constexpr (FMT == 5) {
-        if (__builtin_expect(esc_min == kEscMarker, 0)) {
-#pragma unroll
-            for (int b = 0; b < kT9Runs; ++b)
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    const uint32_t ue = ((uint32_t)K * (rr[b] + (uint32_t)g * cx.H)) & cx.emask;
-                    esc_fix_wave(cfg.tab_esc, cfg.esc_wg_log, cfg.phi_width - 2u, ue, (ld_off<uint8_t>(cx.table, ue) & 0xFu) == kEscMarker, cs[b][g]);
-                }
-        }
-    }
     // (VHDL32: one run at a time -- the 64-bit results of its v_mad_i64_i32 products take register pairs, and left alone the scheduler
     // forms all twelve candidates of the three runs before the first accumulate)
     t9_sum<K, MODE, VHDL32, 0>(cfg, cx, aK, cs, acc);
@@ -258,6 +299,13 @@ __device__ __forceinline__ void t9_finish(const BhwCordicCfg &cfg, const T9Ctx &
     t9_sum<K, MODE, VHDL32, 1>(cfg, cx, aK, cs, acc);
     if constexpr (VHDL32) __builtin_amdgcn_sched_barrier(0);
     t9_sum<K, MODE, VHDL32, 2>(cfg, cx, aK, cs, acc);
+    if constexpr (FMT == 5) {
+        // nibble + escapes: the marker is looked for AFTER the harmonic has been summed (one v_min per gather, one vote and one scalar
+        // branch per harmonic), so that decode and products stay one scheduling region; a wave that met one -- a few per cent of them --
+        // repairs the sums of the marked lanes: minus what the marker's fields gave, plus what the listed pair gives
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(esc_min == kEscMarker) != 0ull, 0))
+            t9_esc_repair<K, MODE, VHDL32>(cfg, cx, rr, aK, acc);
+    }
 #ifdef BHW_X_PAD
     {   // (timing experiment: BHW_X_PAD dummy vector instructions per harmonic, independent of everything else; BHW_X_PADOP 0: VOP2 on
         // registers, 1: a VOP3 form)
@@ -305,6 +353,7 @@ __global__ __launch_bounds__(kT9Threads) __attribute__((amdgpu_waves_per_eu(BHW_
                                                                                            const void *__restrict__ table, int32_t *__restrict__ out)
 {
     static_assert(FMT == 3 || FMT == 5, "one-byte entries");
+
     const uint32_t lq = cfg.phi_width - 2;
     const uint32_t E = 1u << lq, emask = E - 1u, H = E >> 1, hmask = H - 1u;
     const uint32_t W = cfg.dat_width;
@@ -459,7 +508,9 @@ __global__ __launch_bounds__(kT9Threads) __attribute__((amdgpu_waves_per_eu(BHW_
         else store_all(std::false_type{}, std::false_type{});
     } else {
         // Fused apply (emit()): y = (x * w) >> shift, exact 64-bit product like int_multNxN_dsp48.vhd:102.  The 24 samples are requested
-        // together before the first product, nontemporal (read once: streamed past the caches the table lives in).
+        // together before the first product, nontemporal (read once: streamed past the caches the table lives in).  (Requested at the
+        // very start of the wave instead and held in 24 more registers, five waves per SIMD: 0.1569 against 0.1520 ms per window,
+        // profiles/r05_ab_apply_early.txt -- the pass moves 650 MB, it does not wait for its own loads.)
         int32_t xv[kT9Runs][2][4];
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -510,6 +561,11 @@ int bhwk_tile9(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg &w, co
         else           BHW_LAUNCH((k_tile9<M, F, false, V>), grid, block, 0, st, c, w, tp, (const void *)d_table, d_out); \
     } while (0)
     const bool v32 = c.dat_width == 32u;
+#ifdef BHW_T9_ALLFMT5
+    if (fmt == 5 && mode == 0) BHW_T9(0, 5, false);
+    else if (fmt == 5 && mode == 1) BHW_T9(1, 5, false);
+    else
+#endif
     if (fmt == 5) { if (mode == 2 && v32) BHW_T9(2, 5, true); else return (int)hipErrorInvalidValue; }
     else if (mode == 0) BHW_T9(0, 3, false);
     else if (mode == 1) BHW_T9(1, 3, false);

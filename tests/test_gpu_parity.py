@@ -607,6 +607,17 @@ def test_packed_table_is_exact(torch, golden):
         for o in outs[1:]:
             assert bool((o == outs[0]).all()), (win, pw, w, model)
         del outs
+    # the VHDL cosine-sum over the same formats (k_tile9's one-instruction products at 32 bits, plain nibbles and nibble + escapes -- the
+    # VHDL CORDIC's table lists ~900 entries: the end-of-harmonic repair of marked lanes runs in a few per cent of the waves -- and
+    # the general rounding below 32 bits)
+    for win, pw, w, model in ((7, 26, 32, 2), (7, 26, 32, 0), (7, 26, 32, 1), (7, 26, 30, 2)):
+        p = B.make_params(win, pw, w, model=model, combine=B.COMBINE_VHDL)
+        outs = [bhw.generate(p, 0, 1 << pw, algo=B.ALGO_TABLE, table_format=f) for f in (B.TABLE_PLAIN, B.TABLE_NIBBLE_ESC, B.TABLE_BEST)]
+        for o in outs[1:]:
+            assert bool((o == outs[0]).all()), (win, pw, w, model, "vhdl sum")
+        for a in (0, (1 << pw) // 2 - 2048, (1 << pw) - 4096):
+            assert np.array_equal(outs[0][a:a + 4096].cpu().numpy(), O.generate_mt(O.from_bhw(p), a, 4096)), (win, pw, w, model, a)
+        del outs
 
 
 def test_nibble_escape_tables_in_every_tile_path(torch):
