@@ -107,20 +107,22 @@ def sources_sha16():
 
 
 def read_sclk(index=0):
-    """Current shader clock of GPU `index` in MHz from sysfs (pp_dpm_sclk: the level marked '*'), or None where the file is not
-    readable: clock evidence that does not depend on the driver's coarse gpu_busy sampling."""
+    """Highest current shader clock (MHz) over the GPUs sysfs lists (pp_dpm_sclk: the level marked '*'), or None where nothing is
+    readable.  A box may list more cards than HIP shows this process and in another order, so the rank's own card is not picked by
+    index: the card running this benchmark's load is the one at the top.  Clock evidence that does not depend on the driver's coarse
+    gpu_busy sampling."""
     import glob
-    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
-    if not cards:
-        return None
-    try:
-        with open(cards[min(index, len(cards) - 1)]) as f:
-            for line in f:
-                if line.rstrip().endswith("*"):
-                    return int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
-    except Exception:
-        return None
-    return None
+    best = None
+    for path in glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"):
+        try:
+            with open(path) as f:
+                for line in f:
+                    if line.rstrip().endswith("*"):
+                        mhz = int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+                        best = mhz if best is None or mhz > best else best
+        except Exception:
+            continue
+    return best
 
 
 def pmc_traffic():
@@ -576,21 +578,24 @@ def main():
     # the same K steps straight after W warm-up steps, BEFORE the ramp: what a cold device gives (DVFS), printed beside the
     # ramped figure so the effect of the ramp is in the record and not in prose
     no_ramp_elapsed = timed_steps(step, args.steps, args.warmup, barrier, torch.cuda.synchronize, allreduce_max)
-    sclk_cold = read_sclk(local_rank)
     t_ramp = time.perf_counter()
     ramp_steps = 0
+    sclk_before = None
     while time.perf_counter() - t_ramp < args.ramp_seconds:
         for _ in range(50):
             step()
         ramp_steps += 50
+        sclk_before = read_sclk(local_rank)        # sampled while the 50 steps just enqueued are running: the clock under this load
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     ev0.record()                                   # torch creates the HIP event handle at the first record(): not inside the timed region
     ev1.record()                                   # (two hipEventCreate calls cost ~25 us there -- 1 % of a 20-step run)
-    sclk_before = read_sclk(local_rank)
     elapsed = timed_steps(step_with_events, args.steps, 0, barrier, torch.cuda.synchronize, allreduce_max)
+    for _ in range(50):                            # (outside the timed region) the same load again, sampled while it runs
+        step()
     sclk_after = read_sclk(local_rank)
+    torch.cuda.synchronize()
     own_dev_ms = ev0.elapsed_time(ev1) / args.steps
     dev_ms = allreduce_max(own_dev_ms)
     group = group_record(dist, torch, dev if args.backend == "nccl" else "cpu", world, args.backend, own_dev_ms)
@@ -687,7 +692,7 @@ def main():
         # counted bytes beside every leg (profiles/pmc_legs_latest.json, hash-tied to the kernel sources)
         cited, cited_src = pmc_legs_traffic()
         alias = {"C2_bh4_2^20_24bit_per_call": "C2_bh4_2^20_24bit", "C2_bh4_2^20_24bit_graph": "C2_bh4_2^20_24bit",
-                 "C2_bh4_2^20_24bit_graph_4streams": "C2_bh4_2^20_24bit", "C3_two_streams": "headline_C3"}
+                 "C2_bh4_2^20_24bit_graph_4streams": "C2_bh4_2^20_24bit", "C3_two_streams": "headline_C3", "bh7_2^16_32bit_graph": "bh7_2^16_32bit"}
         for name, leg in legs.items():
             c = cited.get(alias.get(name, name))
             if isinstance(leg, dict) and "ms" in leg:
@@ -735,8 +740,10 @@ def main():
         "ranks_seen": group["ranks_seen"], "device_ms_per_step_by_rank": group["device_ms_per_step_by_rank"], "backend": group["backend"],
         "scratch_bytes": int(workspace.numel()) if workspace is not None else 0,
         "library_scratch_bytes": lib_scratch,
-        "sclk_mhz": {"before_timed_region": sclk_before, "after_timed_region": sclk_after, "after_no_ramp_leg": sclk_cold,
-                     "source": "sysfs pp_dpm_sclk of this rank's GPU (None: not readable on this box)"},
+        "sclk_mhz": {"end_of_ramp": sclk_before, "after_timed_region": sclk_after,
+                     "source": "sysfs pp_dpm_sclk (highest over the cards listed), read by the host while 50 enqueued steps are running -- at the end of "
+                               "the ramp (just before the W warm-up + K timed steps) and right after the timed region (None: not readable on "
+                               "this box; an idle device reads ~100 MHz)"},
         "strong": strong_rec,
         "parity_spot_check": parity,
         "cpp_model": cpp_leg,

@@ -287,6 +287,18 @@ __device__ __forceinline__ void t9_finish(const BhwCordicCfg &cfg, const T9Ctx &
                                           const int32_t aK, int32_t (&acc)[kT9Runs][2][4])
 {
     constexpr int NG = (K & 1) ? 2 : 1;
+#ifdef BHW_X_NOALU
+    {   // (timing experiment: the pass's memory operations -- the same gathers, the same 24 stores -- without its arithmetic: every sum
+        // takes one add per gather; no records, no products)
+#pragma unroll
+        for (int b = 0; b < kT9Runs; ++b)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[b][h][j] += (int32_t)e[b][(K & 1) ? h : 0];
+        return;
+    }
+#endif
     int2 cs[kT9Runs][2];
     uint32_t esc_min = 15u;
     t9_run<K, MODE, FMT, 0>(cx, wbase, rr, e, cs, esc_min);

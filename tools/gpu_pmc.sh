@@ -34,7 +34,7 @@ step=0.0
 plan=json.load(open("gpurun_out/pmc_${tag}_1.json"))["config"]["plan"]
 heads=[s.strip().split(" ")[0].replace(",", ", ").replace(">", "") for s in plan.split(": ",1)[1].split(" + ")]
 for k,v in summary.items():
-    if "bhw" not in k.lower() and "k_table" not in k and "k_direct" not in k and "k_fold" not in k: continue   # only this library's kernels
+    if "bhw" not in k.lower() and "k_table" not in k and "k_direct" not in k and "k_fold" not in k and "k_tile9" not in k: continue   # only this library's kernels
     f=2*1024*v.get("FETCH_SIZE",{}).get("mean",0.0); w=1024*v.get("WRITE_SIZE",{}).get("mean",0.0)
     v["hbm_bytes_per_launch"]={"read":f,"write":w,"total":f+w}
     if any(k.startswith(h) for h in heads):

@@ -55,7 +55,7 @@ for j in range(1, len(PL.LEGS) + 1):
                     "traffic_over_algorithmic": (tot_w + tot_r) / info["algorithmic_bytes"] if info["algorithmic_bytes"] else None}
         print("%-28s write %8.1f MB  read %8.1f MB  (algorithmic %8.1f MB)  %s" % (leg, tot_w / 1e6, tot_r / 1e6, info["algorithmic_bytes"] / 1e6, list(ks)))
 out["_meta"] = {"date": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"), "sources_sha16": bench.sources_sha16(),
-                "command": "rocprofv3 --kernel-trace --pmc <set> -- python tools/pmc_legs.py <leg> (4 counter sets x 9 legs, one process each: several legs launch kernels of the same name)",
+                "command": "rocprofv3 --kernel-trace --pmc <set> -- python tools/pmc_legs.py <leg> (4 counter sets x 10 legs, one process each: several legs launch kernels of the same name)",
                 "units": "bytes per launch: WRITE_SIZE KiB x 1024; FETCH_SIZE KiB x 1024 x 2 (gfx950 counts a 128-B request as 64 B)"}
 json.dump(out, open("gpurun_out/pmc_legs_latest.json", "w"), indent=1, sort_keys=True)
 PY

@@ -2,7 +2,7 @@
 # Round artefacts in one GPU call: full GPU suite, hardware-counter passes (headline + every extra leg), bench (default + driver-style
 # short runs), rocprofv3 kernel stats (headline step alone, and the default command with all legs).
 # usage (GPU box, repo root): bash tools/gpu_round.sh <tag>
-tag=${1:-r04}
+tag=${1:-r05}
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout -k 10 900 python -m pytest tests -m gpu -q --durations=12 > gpurun_out/pytest_$tag.log 2>&1

@@ -25,7 +25,7 @@ def kernels_of(plan, extra=()):
 
 
 LEGS = ("headline_C3", "C2_bh4_2^20_24bit", "C4_1024x_bh4_2^16_24bit", "bh7_2^26_16bit_cpp", "taylor_hamming_2^26_16bit", "C3_vhdl_cosine_sum",
-        "C3_vhdl_cordic_and_sum", "C3_model_cpp", "fused_apply_C3")
+        "C3_vhdl_cordic_and_sum", "C3_model_cpp", "fused_apply_C3", "bh7_2^16_32bit")
 
 
 def main(which):
@@ -68,6 +68,9 @@ def main(which):
     elif which == "C3_model_cpp":
         p = bhw.make_params(7, 26, 32, model=B.MODEL_CPP)
         leg(lambda: bhw.generate(p, 0, N26, out=out), lambda: B.describe_plan(p, 0, N26), N26)
+    elif which == "bh7_2^16_32bit":
+        p = bhw.make_params(7, 16, 32)
+        leg(lambda: bhw.generate(p, 0, 1 << 16, out=out[:1 << 16]), lambda: B.describe_plan(p, 0, 1 << 16), 1 << 16)
     elif which == "fused_apply_C3":
         x = torch.randint(-(1 << 31), (1 << 31) - 1, (N26,), dtype=torch.int32, device="cuda")
         p = bhw.make_params(7, 26, 32)
