@@ -262,7 +262,11 @@ __device__ __forceinline__ void t9_issue(const T9Ctx &cx, const uint32_t (&rr)[k
 #ifdef BHW_X_HOT
         const uint32_t voff = th & 0xFFFCu;                                   // (timing experiment: every gather inside 64 KiB)
 #else
+#ifdef BHW_X_NOWRAPS
+        const uint32_t voff = th & cx.emask;                                  // (timing experiment: waves that wrap stay on this path -- every offset masked)
+#else
         const uint32_t voff = K <= 2 ? th : th & cx.emask;                    // K (r + g E/2) < E for K <= 2: nothing to wrap
+#endif
 #endif
         e[b][0] = t9_load<K>(cx.table, voff);
         if constexpr ((K & 1) != 0) {
@@ -272,21 +276,23 @@ __device__ __forceinline__ void t9_issue(const T9Ctx &cx, const uint32_t (&rr)[k
 #else
             const int32_t dist = (int32_t)(s1 & cx.emask) - (int32_t)(s0 & cx.emask);
 #endif
+#ifdef BHW_X_NOWRAPS
+            e[b][1] = t9_load<K>(cx.table, (voff + (uint32_t)dist) & cx.emask & ~3u);
+#else
             e[b][1] = t9_load<K>(reinterpret_cast<const char *>(cx.table) + dist, voff);
+#endif
         }
 #endif
     }
 }
 
-// Nibble + escapes: one test per harmonic (the minimum of its low fields is the marker); the listed entries are a few per 100 000, the
-// branch is almost never taken; a marked lane is resolved on the scalar unit (esc_fix_wave).  (Measured alternatives, profiles/HISTORY.md
-// round 5: the marker only recorded and a marked wave -- 5 - 9 % of them -- started over on the general path: 73.9 against 68.7 us for
-// the cpp model; a second, fixing copy of this path for those waves: the kernel spills.)
+// Nibble + escapes: the marker is looked for AFTER the harmonic has been summed (one v_min per gather, one vote and one scalar branch
+// per harmonic), so that decode and products stay one scheduling region; a wave that met one -- a few per cent of them: the listed
+// entries are a few per 100 000 -- repairs the sums of the marked lanes (t9_esc_repair).
 template <int K, int MODE, int FMT, bool VHDL32>
 __device__ __forceinline__ void t9_finish(const BhwCordicCfg &cfg, const T9Ctx &cx, const uint32_t wbase, const uint32_t (&rr)[kT9Runs], const uint32_t (&e)[kT9Runs][2],
                                           const int32_t aK, int32_t (&acc)[kT9Runs][2][4])
 {
-    constexpr int NG = (K & 1) ? 2 : 1;
 #ifdef BHW_X_NOALU
     {   // (timing experiment: the pass's memory operations -- the same gathers, the same 24 stores -- without its arithmetic: every sum
         // takes one add per gather; no records, no products)
@@ -312,11 +318,7 @@ __device__ __forceinline__ void t9_finish(const BhwCordicCfg &cfg, const T9Ctx &
     if constexpr (VHDL32) __builtin_amdgcn_sched_barrier(0);
     t9_sum<K, MODE, VHDL32, 2>(cfg, cx, aK, cs, acc);
     if constexpr (FMT == 5) {
-        // nibble + escapes: the marker is looked for AFTER the harmonic has been summed (one v_min per gather, one vote and one scalar
-        // branch per harmonic), so that decode and products stay one scheduling region; a wave that met one -- a few per cent of them --
-        // repairs the sums of the marked lanes: minus what the marker's fields gave, plus what the listed pair gives
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(esc_min == kEscMarker) != 0ull, 0))
-            t9_esc_repair<K, MODE, VHDL32>(cfg, cx, rr, aK, acc);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(esc_min == kEscMarker) != 0ull, 0)) t9_esc_repair<K, MODE, VHDL32>(cfg, cx, rr, aK, acc);
     }
 #ifdef BHW_X_PAD
     {   // (timing experiment: BHW_X_PAD dummy vector instructions per harmonic, independent of everything else; BHW_X_PADOP 0: VOP2 on
@@ -336,29 +338,52 @@ __device__ __forceinline__ void t9_finish(const BhwCordicCfg &cfg, const T9Ctx &
 
 // A wave one of whose runs wraps around the ring, or one of whose harmonics crosses a quarter turn inside a run (1.6 % of the
 // waves of a 2^26-point window): records from the table's record array, per-lane quadrants -- the general arithmetic of
-// k_table_combine_tile's global path.
+// k_table_combine_tile's global path.  Nibble + escapes: every entry of the harmonic is read as plain nibbles first and the listed
+// pairs are fetched afterwards, NOT by a test per gather (tab_fetch): that test is control flow between a lane's loads, it
+// serialises the 54 of them, and these few waves then live so long that they hold the whole pass back -- 71.6 against 65.2 us for
+// the VHDL product window with every wave forced onto the hot path (profiles/r05_ab_tile9_slow_path.txt).
 template <int K, int MODE, int FMT>
 __device__ __forceinline__ void t9_harmonic_slow(const BhwCordicCfg &cfg, const void *__restrict__ table, const uint32_t (&rr)[kT9Runs], uint32_t lq,
                                                  const int32_t aK, uint32_t W, int32_t (&acc)[kT9Runs][2][4])
 {
     constexpr int NG = (K & 1) ? 2 : 1;
     const uint32_t E = 1u << lq, emask = E - 1u, H = E >> 1;
+    int2 cs[kT9Runs][2];
+    uint32_t marked = 0u;                                              // bit 2 b + g: that gather read a marker
+#pragma unroll
+    for (int b = 0; b < kT9Runs; ++b)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const uint32_t u = ((uint32_t)K * (rr[b] + (uint32_t)g * H)) & emask;
+            const uint32_t e = ld_off<uint8_t>(table, u);
+            const int2 p = tab_predict_nib(ld_off<int4>(cfg.tab_coarse, (u >> kT9D) << 4), u & ((1u << kT9D) - 1u), kT9D), n = nib_fields(e);
+            cs[b][g] = make_int2(p.x + n.x, p.y + n.y);
+            if constexpr (FMT == 5) marked |= ((e & 0xFu) == kEscMarker ? 1u : 0u) << (2 * b + g);
+        }
+    if constexpr (FMT == 5) {
+        if (__builtin_expect(marked != 0u, 0)) {                       // (per lane: the few that hold a listed entry)
+#pragma unroll
+            for (int b = 0; b < kT9Runs; ++b)
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+                    if ((marked >> (2 * b + g)) & 1u)
+                        cs[b][g] = esc_lookup(cfg.tab_esc, cfg.esc_wg_log, lq, ((uint32_t)K * (rr[b] + (uint32_t)g * H)) & emask);
+        }
+    }
 #pragma unroll
     for (int b = 0; b < kT9Runs; ++b) {
         int32_t sv[4];
         const uint32_t t0 = (uint32_t)K * rr[b];
-        tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0), true>(cfg, aK, W, tab_fetch<FMT>(cfg, table, t0 & emask, t0 & emask), t0 >> lq, sv);
+        tile_harmonic<K, MODE, ring_qbase(K, 0), ring_qbits(K, 0), true>(cfg, aK, W, cs[b][0], t0 >> lq, sv);
         tile_accumulate<K, 0, true>(sv, acc[b][0]);
         if constexpr (NG == 2) {
             const uint32_t t1 = (uint32_t)K * (rr[b] + H);
-            tile_harmonic<K, MODE, ring_qbase(K, 1), ring_qbits(K, 1), true>(cfg, aK, W, tab_fetch<FMT>(cfg, table, t1 & emask, t1 & emask), t1 >> lq, sv);
+            tile_harmonic<K, MODE, ring_qbase(K, 1), ring_qbits(K, 1), true>(cfg, aK, W, cs[b][1], t1 >> lq, sv);
             tile_accumulate<K, 0, true>(sv, acc[b][1]);
         } else tile_accumulate<K, K / 2, true>(sv, acc[b][1]);
     }
 }
 
-// Lane r in [0, E/2) owns the eight coefficients n = r + h*E/2 + j*E (h = 0, 1; j = 0..3), E = N/4 table entries (see
-// k_table_combine_tile); thread = three inv3-sibling runs of the 15-run tile, 24 sums.
 // VHDL32: MODE 2 at dat_width 32 (t9_products); false for the HLS rule.
 template <int MODE, int FMT, bool APPLY, bool VHDL32 = false>
 __global__ __launch_bounds__(kT9Threads) __attribute__((amdgpu_waves_per_eu(BHW_T9_WAVES))) void k_tile9(BhwCordicCfg cfg, BhwWinCfg win, BhwTilePlan tp,
@@ -404,6 +429,9 @@ __global__ __launch_bounds__(kT9Threads) __attribute__((amdgpu_waves_per_eu(BHW_
         st = lane == 27u ? st0 : st;
         const bool w = lane < 27u ? (th0 & emask) + K * (uint32_t)(kT9Threads - 1) > emask : lane < 30u ? st + (uint32_t)kT9Threads > H : false;
         wraps = __builtin_amdgcn_ballot_w64(w) != 0ull;
+#ifdef BHW_X_NOWRAPS
+        wraps = false;                                                        // (timing experiment: every wave on the hot path)
+#endif
         const uint32_t q = th0 >> lq;
         qm0 = __builtin_amdgcn_ballot_w64((q & 1u) != 0u);
         qm1 = __builtin_amdgcn_ballot_w64((q & 2u) != 0u);
@@ -447,17 +475,15 @@ __global__ __launch_bounds__(kT9Threads) __attribute__((amdgpu_waves_per_eu(BHW_
     // pre-shifted weights: (a_k * v) >> (W-2) is the high half of (a_k << (34-W)) * v (tile_harmonic FAST; the launcher checks the bound)
     auto weight = [&](int k) -> int32_t { return (int32_t)((uint32_t)win.aa[k] << (34u - W)); };
     if (!wraps) {
-        T9Ctx cx{table, reinterpret_cast<const char *>(ring), H, emask, qm0, qm1, W, {st0, st1, st2}};
+        const T9Ctx cx{table, reinterpret_cast<const char *>(ring), H, emask, qm0, qm1, W, {st0, st1, st2}};
         uint32_t wbase;
         asm volatile("v_mov_b32 %0, %1" : "=v"(wbase) : "s"(wave << kT9WaveLog));
-        // (the scheduling fences keep each harmonic's loads next to its arithmetic: merged into one region the six harmonics' 27 loads
-        // are hoisted to the top and the kernel runs out of registers -- profiles/HISTORY.md, round 4)
-        uint32_t e[kT9Runs][2];
         // The harmonics are kept apart by real branches on the term count (7 here: always true), as in k_table_combine_tile: merged
         // into one region their 27 loads are hoisted to the top and the kernel runs out of registers.  (Scheduling fences alone --
-        // __builtin_amdgcn_sched_barrier -- do hold the loads, but not the earlier passes' code motion across the escape test of the
-        // nibble + escapes format, and the register allocation is worse with them: 79 against 62 registers for the VHDL-rule
-        // instance.  A software pipeline -- harmonic K + 1's bytes requested before harmonic K is worked on -- measured: nothing.)
+        // __builtin_amdgcn_sched_barrier -- do hold the loads, but the register allocation is worse with them: 79 against 62 registers
+        // for the VHDL-rule instance.  A software pipeline -- harmonic K + 1's bytes requested before harmonic K is worked on --
+        // measured: nothing.)
+        uint32_t e[kT9Runs][2];
 #define BHW_T9_HARMONIC(K) if (win.n_terms > K) { t9_issue<K>(cx, rr, e); t9_finish<K, MODE, FMT, VHDL32>(cfg, cx, wbase, rr, e, weight(K), acc); __builtin_amdgcn_sched_barrier(0); }
         BHW_T9_HARMONIC(1) BHW_T9_HARMONIC(2) BHW_T9_HARMONIC(3) BHW_T9_HARMONIC(4) BHW_T9_HARMONIC(5) BHW_T9_HARMONIC(6)
 #undef BHW_T9_HARMONIC
