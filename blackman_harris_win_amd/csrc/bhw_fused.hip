@@ -13,10 +13,11 @@ namespace {
 // 20-call graph, BH-4 2^22 15.3 -> 13.1 us, BH-3 2^22 / 20-bit 10.2 -> 8.1 us (profiles/r04_short_windows_store_scope.txt).  Longer
 // ones (explicit BHW_ALGO_FUSED up to phi_width 30, ownership parts of 2^26-point windows) keep write-back stores: at agent scope the
 // tile kernel's 268 MB took 91 instead of 67 us (profiles/r04_ab_store_scope.txt) -- the same rule as k_table_combine_tile / k_tile9.
-__device__ __forceinline__ void emit_f(const BhwWinCfg &win, int32_t *__restrict__ out, uint64_t idx, int32_t w, bool through)
+template <bool THROUGH>
+__device__ __forceinline__ void emit_f(const BhwWinCfg &win, int32_t *__restrict__ out, uint64_t idx, int32_t w)
 {
     if (win.apply_x) w = (int32_t)(((int64_t)__builtin_nontemporal_load(&win.apply_x[idx]) * (int64_t)w) >> win.apply_shift);
-    if (through) asm volatile("global_store_dword %0, %1, off sc1" :: "v"(out + idx), "v"(w) : "memory");   // (wave-uniform)
+    if constexpr (THROUGH) asm volatile("global_store_dword %0, %1, off sc1" :: "v"(out + idx), "v"(w) : "memory");
     else out[idx] = w;
 }
 
@@ -448,10 +449,18 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win, BhwFo
             else vout[h][j] = (int32_t)((uint32_t)acc[h][j] << (32u - W)) >> (32u - W);   // (win_t)(...) wrap to W bits
         }
     if (plan.frames <= 1u) {                                              // scalar
+        // (ONE wave-uniform branch around the eight stores, not one per store: the short windows count tenths of a microsecond)
+        if (plan.phi_width <= 24u) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) emit_f(win, out, (uint64_t)(r + (uint32_t)h * H) + (uint64_t)j * E, vout[h][j], plan.phi_width <= 24u);
+                for (int j = 0; j < 4; ++j) emit_f<true>(win, out, (uint64_t)(r + (uint32_t)h * H) + (uint64_t)j * E, vout[h][j]);
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) emit_f<false>(win, out, (uint64_t)(r + (uint32_t)h * H) + (uint64_t)j * E, vout[h][j]);
+        }
         return;
     }
     // Batched identical frames (bhw_generate_batched_device: the coefficient stream is periodic, src/bh_win_7term.vhd:92-97): the
@@ -488,12 +497,16 @@ __device__ __forceinline__ void rot_step_lat(int64_t &x, int64_t &y, int32_t &z,
     y += (int64_t)sg * (int64_t)xs;
 }
 
-template <int NTERMS, int MODE>
-__global__ __launch_bounds__(256) void k_fold_split(BhwWinCfg win, BhwFoldPlan plan, int32_t *__restrict__ out)
+// SW = waves per 64 ring lanes.  Round 5: one chain per wave (SW = the chain count, 576 threads for a 7-term window) instead of four
+// waves with up to three chains each: a launch this short has about one wave per SIMD either way, so what counts is the serial
+// depth of a wave -- one chain's dependent rotations instead of three chains' worth of issue (profiles/r05_short_windows_split.txt).
+template <int NTERMS, int MODE, int SW>
+__global__ __launch_bounds__(64 * SW) void k_fold_split(BhwWinCfg win, BhwFoldPlan plan, int32_t *__restrict__ out)
 {
     using acc_t = typename std::conditional<MODE == 2, Sum32, int32_t>::type;
     constexpr int NCH = fold_chains(NTERMS);
-    constexpr int MAXC = (NCH + 3) / 4;                                   // chains per wave
+    static_assert(SW >= 2 && SW <= 16, "waves 0 and 1 sum the two half-period images");
+    constexpr int MAXC = (NCH + SW - 1) / SW;                             // chains per wave
     __shared__ int2 cs_s[NCH][64];
     BhwCordicCfg cfg;                                                     // tile_harmonic() reads ones_neg only
     cfg.ones_neg = plan.ones_neg;
@@ -518,13 +531,13 @@ __global__ __launch_bounds__(256) void k_fold_split(BhwWinCfg win, BhwFoldPlan p
     auto chain_K = [](uint32_t c) { return 2u * (c / 3u) + 1u + (c % 3u == 2u ? 1u : 0u); };
     auto chain_h = [](uint32_t c) { return (c % 3u == 1u) ? 1u : 0u; };
 
-    // ---- phase 1: lane i < MAXC runs the shared prefix of this wave's chain i (chain index wave + 4 i) ----
+    // ---- phase 1: lane i < MAXC runs the shared prefix of this wave's chain i (chain index wave + SW i) ----
     int64_t px = plan.x0, py = plan.x0;
     uint32_t pdz = 0u;
     int pk = 1;
     {
         const uint32_t ci = lane < (uint32_t)MAXC ? lane : 0u;
-        uint32_t c = wave + 4u * ci;
+        uint32_t c = wave + (uint32_t)SW * ci;
         if (c >= (uint32_t)NCH) c = wave < (uint32_t)NCH ? wave : 0u;     // idle lanes / waves repeat a valid chain
         const uint32_t K = chain_K(c), hodd = chain_h(c);
         const uint32_t t0 = (K * wg_r0 + hodd * H) & emask;
@@ -555,7 +568,7 @@ __global__ __launch_bounds__(256) void k_fold_split(BhwWinCfg win, BhwFoldPlan p
     int kc = 32;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
-        const uint32_t c = wave + 4u * (uint32_t)i;
+        const uint32_t c = wave + (uint32_t)SW * (uint32_t)i;
         const uint32_t cc = c < (uint32_t)NCH ? c : 0u;
         const uint32_t xl = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)px, i), xh = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)px >> 32), i);
         const uint32_t yl = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)py, i), yh = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)py >> 32), i);
@@ -584,7 +597,7 @@ __global__ __launch_bounds__(256) void k_fold_split(BhwWinCfg win, BhwFoldPlan p
     }
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
-        const uint32_t c = wave + 4u * (uint32_t)i;
+        const uint32_t c = wave + (uint32_t)SW * (uint32_t)i;
         if (c < (uint32_t)NCH) cs_s[c][lane] = make_int2((int32_t)(x[i] >> out_shr), (int32_t)(y[i] >> out_shr));
     }
     __syncthreads();
@@ -614,12 +627,18 @@ __global__ __launch_bounds__(256) void k_fold_split(BhwWinCfg win, BhwFoldPlan p
         }
         BHW_FS_HARMONIC(1) BHW_FS_HARMONIC(2) BHW_FS_HARMONIC(3) BHW_FS_HARMONIC(4) BHW_FS_HARMONIC(5) BHW_FS_HARMONIC(6)
 #undef BHW_FS_HARMONIC
+        int32_t v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            int32_t v;
-            if constexpr (MODE == 2) v = w32_final<BHW_COMBINE_VHDL>(acc[j], W, NTERMS);
-            else v = (int32_t)((uint32_t)acc[j] << (32u - W)) >> (32u - W);
-            emit_f(win, out, (uint64_t)(r + (uint32_t)HH * H) + (uint64_t)j * E, v, plan.phi_width <= 24u);
+            if constexpr (MODE == 2) v[j] = w32_final<BHW_COMBINE_VHDL>(acc[j], W, NTERMS);
+            else v[j] = (int32_t)((uint32_t)acc[j] << (32u - W)) >> (32u - W);
+        }
+        if (plan.phi_width <= 24u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) emit_f<true>(win, out, (uint64_t)(r + (uint32_t)HH * H) + (uint64_t)j * E, v[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) emit_f<false>(win, out, (uint64_t)(r + (uint32_t)HH * H) + (uint64_t)j * E, v[j]);
         }
     };
     if (wave == 0u) combine(std::integral_constant<int, 0>{});
@@ -685,7 +704,8 @@ int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg 
     }
     const dim3 grid(wg, gy), blk(block);
     plan.k24 = bhwp_fold_k24(c);
-    dim3 grid_s(0), blk_s(256);
+    const uint32_t split_waves = (uint32_t)(w.n_terms == 2 ? 2 : w.n_terms == 3 ? 3 : w.n_terms == 4 ? 5 : w.n_terms == 5 ? 6 : 9);   // fold_chains(): one chain per wave
+    dim3 grid_s(0), blk_s(64u * split_waves);
     if (split) {
         uint32_t wgs = 0;
         for (uint32_t i = 0; i < n_runs; ++i) {
@@ -697,7 +717,7 @@ int bhwk_fold_direct(const BhwLaunch &l, const BhwCordicCfg &c, const BhwWinCfg 
     }
 #define BHW_FD_NT_M(NT, M)                                                                                  \
     do {                                                                                                    \
-        if (split) BHW_LAUNCH((k_fold_split<NT, M>), grid_s, blk_s, 0, st, w, plan, d_out);               \
+        if (split) BHW_LAUNCH((k_fold_split<NT, M, fold_chains(NT)>), grid_s, blk_s, 0, st, w, plan, d_out); \
         else if (narrow)   BHW_LAUNCH((k_fold_direct<NT, M, 2>), grid, blk, 0, st, w, plan, d_out);      \
         else if (lockstep) BHW_LAUNCH((k_fold_direct<NT, M, 1>), grid, blk, 0, st, w, plan, d_out);      \
         else               BHW_LAUNCH((k_fold_direct<NT, M, 0>), grid, blk, 0, st, w, plan, d_out);      \

@@ -501,13 +501,17 @@ int bhwp_fold_form(const BhwCordicCfg &c, const BhwWinCfg &w, uint64_t total)
     // every launch size: where the chip is full the form still wins a little over the 64-bit one with its own split level per chain
     // (BH-4 2^22 / 24-bit 16.1 -> 15.2 us, BH-5 17.7 -> 17.4)
     const bool narrow = c.dat_width + c.out_shr <= 30u && c.phi_width - 2u - c.z_shr + c.z_shl <= 30u;
-    // short launches, form of the kernel: chains split over four waves per 64 lanes (k_fold_split), lockstep, or sequential.
+    // short launches, form of the kernel: one chain per wave over the same 64 lanes (k_fold_split), lockstep, or sequential.
     // measured per call (profiles/r02_ab_fused_lockstep.txt): split 7.8 / lockstep 9.0 us at 2^13 lanes (BH-7 2^16), 6.9 / 7.7 at
     // 2^15 (BH-5 2^18), 9.7 / 9.7 at 2^16, 9.0 / 8.2 at 2^17 (BH-4 2^20): split up to 2^15 lanes, lockstep up to 2^18
     // (round 3, tools/bench_short_graph.py: where the narrow form applies it beats the split one at every size for windows of up to
     // five terms -- 4.4 / 4.5 / 4.8 against 5.1 / 5.2 / 5.5 us at 2^14 / 2^16 / 2^18 points of BH-4 -- and loses to it with the nine
     // chains of a 7-term window, 6.8 against 6.6 us at 2^16)
-    if (total <= (1u << 15) && !(narrow && w.n_terms <= 5)) return BHWP_FOLD_SPLIT;
+    // (round 5, one chain per wave in the split form -- profiles/r05_short_windows_split*.txt: 7.1 -> 5.0 us for BH-7 2^16 at 32 bits; it
+    // now also wins one size up for windows of up to five terms, 2^16 lanes: BH-4 2^19 / 32-bit 7.07 -> 6.23 us, BH-3 5.96 -> 5.00, BH-5
+    // 7.35 -> 6.85, while the nine chains of a 7-term window lose there, 9.01 -> 9.50, and everything loses at 2^17 lanes)
+    const uint64_t split_max = w.n_terms <= 5 ? (1u << 16) : (1u << 15);
+    if (total <= split_max && !(narrow && w.n_terms <= 5)) return BHWP_FOLD_SPLIT;
     if (narrow) return BHWP_FOLD_NARROW;
     // fewer than ~4 waves per SIMD in the whole launch: latency-bound, walk the chains in lockstep
     return total <= (1u << 18) ? BHWP_FOLD_LOCKSTEP : BHWP_FOLD_SEQUENTIAL;
@@ -776,7 +780,7 @@ int bhw_describe_plan(const bhw_params *p, uint64_t n0, uint64_t count, const bh
     if (algo == BHW_ALGO_FUSED) {
         // one launch over the whole ring [0, N/8) per period: the form bhwk_fold_direct picks for that many lanes
         const int form = bhwp_fold_form(c, w, 1ull << (p->phi_width - 3));
-        if (form == BHWP_FOLD_SPLIT) snprintf(buf, len, "fused: k_fold_split<%u,%d> (+ k_direct_fast on ragged ends)", p->n_terms, mode_of(c, w));
+        if (form == BHWP_FOLD_SPLIT) snprintf(buf, len, "fused: k_fold_split<%u,%d,%u> (+ k_direct_fast on ragged ends)", p->n_terms, mode_of(c, w), p->n_terms == 2 ? 2u : p->n_terms == 3 ? 3u : p->n_terms == 4 ? 5u : p->n_terms == 5 ? 6u : 9u);
         else snprintf(buf, len, "fused: k_fold_direct<%u,%d,%d> (+ k_direct_fast on ragged ends)", p->n_terms, mode_of(c, w), form);
         return BHW_OK;
     }

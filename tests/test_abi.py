@@ -157,7 +157,7 @@ def test_headline_kernels_have_no_scratch():
         res = json.load(f)
     headline = ["k_tile9<0, 3, false, false>", "k_tile9<2, 3, false, true>", "k_tile9<2, 5, false, true>", "k_tile9<0, 3, true, false>", "k_table_combine_tile<15, 1, 5, true, false>", "k_table_build_mirror<32, 3, 1024>", "k_table_build_mirror<32, 2, 1024>", "k_table_build_mirror<31, 3, 1024>", "k_table_build_mirror<32, 3, 256>", "k_table_combine_tile<15, 2, 3, true, false>", "k_table_combine_tile<15, 0, 3, true, false>",
                 "k_table_combine_tile<15, 0, 2, true, false>", "k_table_combine_tile<15, 1, 2, true, false>", "k_table_combine_tile<15, 0, 2, false, false>",
-                "k_fold_direct<7, 0, 0>", "k_fold_direct<4, 0, 2>", "k_fold_direct<4, 0, 1>", "k_fold_split<4, 0>", "k_runlength_window<7, 1, true>"]
+                "k_fold_direct<7, 0, 0>", "k_fold_direct<4, 0, 2>", "k_fold_direct<4, 0, 1>", "k_fold_split<4, 0, 5>", "k_fold_split<7, 0, 9>", "k_runlength_window<7, 1, true>"]
     for name in headline:
         assert name in res, name
     for name, r in res.items():                                      # no kernel of the library uses scratch
@@ -216,7 +216,9 @@ def test_describe_plan_names_the_fused_kernel_that_runs():
     the state width; the plan line names that one (round-3 advisor finding: it used to print a two-parameter k_fold_direct)."""
     from blackman_harris_win_amd import binding as B
     assert "k_fold_direct<4,0,2>" in B.describe_plan(B.make_params(4, 20, 24), 0, 1 << 20)        # C2: 32-bit-state form
-    assert "k_fold_split<7,0>" in B.describe_plan(B.make_params(7, 16, 32), 0, 1 << 16)           # 2^13 lanes, 64-bit state, 9 chains
+    assert "k_fold_split<7,0,9>" in B.describe_plan(B.make_params(7, 16, 32), 0, 1 << 16)         # 2^13 lanes, 64-bit state, 9 chains: 9 waves
+    assert "k_fold_split<4,0,5>" in B.describe_plan(B.make_params(4, 19, 32), 0, 1 << 19)         # 2^16 lanes, up to five terms: still split
+    assert "k_fold_direct<4,0,1>" in B.describe_plan(B.make_params(4, 20, 32), 0, 1 << 20)        # 2^17 lanes: lockstep
     assert "k_fold_direct<7,0,1>" in B.describe_plan(B.make_params(7, 19, 32), 0, 1 << 19)        # 2^16 lanes: lockstep
     assert "k_fold_direct<4,2,2>" in B.describe_plan(B.make_params(4, 16, 24, combine=B.COMBINE_VHDL), 0, 1 << 16)
     # dropped phase bits but too few coefficients per table entry for the run-length kernel (z_shr 1: 2 < 3 x 16): the table

@@ -159,7 +159,10 @@ for _model in (B.MODEL_HLS, B.MODEL_CPP, B.MODEL_VHDL):
                               # either side of the 32-bit-state form of the fused kernel (dat_width + out_shr <= 30): its in-wave
                               # prefixes, the sign-product rotation from rotation k24 on and the EXEC-masked one before it (waves
                               # whose groups wrap start at rotation 1)
-                              (7, 16, 28), (5, 19, 28), (4, 18, 27), (3, 16, 29), (2, 14, 26), (5, 12, 10)]:
+                              (7, 16, 28), (5, 19, 28), (4, 18, 27), (3, 16, 29), (2, 14, 26), (5, 12, 10),
+                              # 64-bit state, one chain per wave (k_fold_split<.., 2 / 3 / 5 / 6 / 9 waves>): up to 2^16 lanes for
+                              # windows of up to five terms, 2^15 for seven; and the lockstep form just above
+                              (2, 19, 32), (3, 19, 31), (4, 19, 32), (5, 19, 32), (7, 18, 32), (7, 19, 32), (5, 20, 31)]:
             if _model == B.MODEL_HLS and _pw > _w + 2:
                 continue
             FUSED_CASES.append((_model, _combine, _win, _pw, _w))

@@ -13,6 +13,8 @@ import blackman_harris_win_amd as bhw  # noqa: E402
 from blackman_harris_win_amd import binding as B  # noqa: E402
 
 CASES = [(4, 14, 24), (4, 16, 24), (4, 18, 24), (4, 20, 24), (5, 18, 24), (7, 16, 28), (7, 16, 32), (3, 18, 16), (7, 19, 24), (2, 16, 16), (4, 21, 24), (4, 22, 24), (5, 22, 24), (5, 21, 28), (3, 22, 20)]
+if os.environ.get("SHORT_CASES") == "split":                      # where the split form competes with the lockstep / narrow forms
+    CASES = [(5, 19, 32), (3, 19, 32), (3, 20, 32), (2, 20, 32), (2, 21, 32), (4, 20, 32), (5, 20, 32), (7, 14, 32), (7, 16, 32), (7, 17, 32), (7, 18, 32), (7, 19, 32), (7, 17, 24), (7, 18, 24), (5, 16, 32), (5, 18, 32), (4, 18, 32), (4, 19, 32), (3, 18, 32)]
 
 
 def replay_us(gen, p, n, out):
