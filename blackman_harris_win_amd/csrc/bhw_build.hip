@@ -775,8 +775,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
     if constexpr (FMT == 5) {                                        // the list's length; a list that overflowed fails the format
         __syncthreads();
         const uint32_t n_esc = esc_n < kEscFill ? esc_n : kEscFill;
-        if (threadIdx.x < n_esc) {                                   // one lane per listed entry: its slot by open addressing
-            const int4 it = esc_list[threadIdx.x];
+        // (the thread index re-read behind an empty asm: compared as threadIdx.x, the lane masks of the kernel's first lines were kept
+        // alive across the whole kernel for these three tests -- in spilled scalar registers)
+        uint32_t tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        if (tid < n_esc) {                                   // one lane per listed entry: its slot by open addressing
+            const int4 it = esc_list[tid];
             uint32_t h = esc_slot((uint32_t)it.x);
 #pragma unroll 1
             for (uint32_t i = 0; i < kEscSlots; ++i) {
@@ -786,8 +790,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
             }
         }
         __syncthreads();
-        if (threadIdx.x < kEscSlots) reinterpret_cast<int4 *>(plan.tab_esc)[(size_t)blockIdx.x * kEscSlots + threadIdx.x] = esc_tab[threadIdx.x];
-        if (threadIdx.x == 0u && esc_n > kEscFill && plan.check_flag) atomicOr(plan.check_flag, 1u);
+        if (tid < kEscSlots) reinterpret_cast<int4 *>(plan.tab_esc)[(size_t)blockIdx.x * kEscSlots + tid] = esc_tab[tid];
+        if (tid == 0u && esc_n > kEscFill && plan.check_flag) atomicOr(plan.check_flag, 1u);
     }
     BHW_STAMP(5);
 }
