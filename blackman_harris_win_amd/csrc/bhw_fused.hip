@@ -111,32 +111,32 @@ __device__ __forceinline__ void rot_narrow32(int32_t &x, int32_t &y, int32_t &z,
 }
 
 // The same rotation as sign products: x -= sg * (y >> k), y += sg * (x >> k), z -= sg * lut[k] with sg = +1 / -1 in three
-// v_mad_i32_i24 (24-bit factors, 32-bit addend): 8 vector instructions and no EXEC traffic.  Valid from rotation plan.k24 on, where
-// the shifted coordinates and the ROM word fit 24 bits (the launcher derives it from the widths; 2 for a 2^20-point 24-bit window).
-__device__ __forceinline__ void rot_mad24(int32_t &x, int32_t &y, int32_t &z, int k, uint32_t lutk)
+// v_mad_i32_i24 (24-bit factors, 32-bit addend) and no EXEC traffic.  Valid from rotation plan.k24 on, where the shifted coordinates
+// and TWICE the ROM word fit 24 bits (the launcher derives it from the widths; 2 for a 2^20-point 24-bit window).
+// The angle is carried doubled and odd, zz = 2 z + 1 (never 0; z >= 0 <=> zz >= 1), so that the sign is ONE instruction,
+// sg = med3(zz, -1, 1): 7 vector instructions per rotation instead of 8 (shift-sign, or 1, negate before).  lut2 = 2 * lut[k].
+__device__ __forceinline__ void rot_mad24(int32_t &x, int32_t &y, int32_t &zz, int k, uint32_t lut2)
 {
     int32_t a, b, sg, ng;
-    asm volatile("v_ashrrev_i32 %[ng], 31, %[z]\n\t"
+    asm volatile("v_med3_i32 %[sg], %[z], -1, 1\n\t"
                  "v_ashrrev_i32 %[a], %[k], %[y]\n\t"
                  "v_ashrrev_i32 %[b], %[k], %[x]\n\t"
-                 "v_or_b32 %[sg], 1, %[ng]\n\t"
                  "v_sub_u32 %[ng], 0, %[sg]\n\t"
-                 "v_mad_i32_i24 %[x], %[ng], %[a], %[x]\n\t"
                  "v_mad_i32_i24 %[y], %[sg], %[b], %[y]\n\t"
+                 "v_mad_i32_i24 %[x], %[ng], %[a], %[x]\n\t"
                  "v_mad_i32_i24 %[z], %[ng], %[l], %[z]"
-                 : [x] "+v"(x), [y] "+v"(y), [z] "+v"(z), [a] "=&v"(a), [b] "=&v"(b), [sg] "=&v"(sg), [ng] "=&v"(ng)
-                 : [l] "s"(lutk), [k] "s"(k));
+                 : [x] "+v"(x), [y] "+v"(y), [z] "+v"(zz), [a] "=&v"(a), [b] "=&v"(b), [sg] "=&v"(sg), [ng] "=&v"(ng)
+                 : [l] "s"(lut2), [k] "s"(k));
 }
 
 // Two / three chains in one statement, instruction by instruction side by side: a wave issues in order, and with one or two waves
-// per SIMD (a 2^20-point window is 2 048 waves on 1 024 SIMDs) the four dependent steps of a rotation (sign, +-1, negate, product)
+// per SIMD (a 2^20-point window is 2 048 waves on 1 024 SIMDs) the dependent steps of a rotation (sign, negate, product)
 // stall it unless other chains' instructions sit in between.
-__device__ __forceinline__ void rot_mad24_x2(int32_t &x0, int32_t &y0, int32_t &z0, int32_t &x1, int32_t &y1, int32_t &z1, int k, uint32_t lutk)
+__device__ __forceinline__ void rot_mad24_x2(int32_t &x0, int32_t &y0, int32_t &z0, int32_t &x1, int32_t &y1, int32_t &z1, int k, uint32_t lut2)
 {
     int32_t a0, b0, s0, n0, a1, b1, s1, n1;
-    asm volatile("v_ashrrev_i32 %[n0], 31, %[z0]\n\tv_ashrrev_i32 %[n1], 31, %[z1]\n\t"
+    asm volatile("v_med3_i32 %[s0], %[z0], -1, 1\n\tv_med3_i32 %[s1], %[z1], -1, 1\n\t"
                  "v_ashrrev_i32 %[a0], %[k], %[y0]\n\tv_ashrrev_i32 %[a1], %[k], %[y1]\n\t"
-                 "v_or_b32 %[s0], 1, %[n0]\n\tv_or_b32 %[s1], 1, %[n1]\n\t"
                  "v_ashrrev_i32 %[b0], %[k], %[x0]\n\tv_ashrrev_i32 %[b1], %[k], %[x1]\n\t"
                  "v_sub_u32 %[n0], 0, %[s0]\n\tv_sub_u32 %[n1], 0, %[s1]\n\t"
                  "v_mad_i32_i24 %[y0], %[s0], %[b0], %[y0]\n\tv_mad_i32_i24 %[y1], %[s1], %[b1], %[y1]\n\t"
@@ -144,15 +144,14 @@ __device__ __forceinline__ void rot_mad24_x2(int32_t &x0, int32_t &y0, int32_t &
                  "v_mad_i32_i24 %[z0], %[n0], %[l], %[z0]\n\tv_mad_i32_i24 %[z1], %[n1], %[l], %[z1]"
                  : [x0] "+v"(x0), [y0] "+v"(y0), [z0] "+v"(z0), [x1] "+v"(x1), [y1] "+v"(y1), [z1] "+v"(z1),
                    [a0] "=&v"(a0), [b0] "=&v"(b0), [s0] "=&v"(s0), [n0] "=&v"(n0), [a1] "=&v"(a1), [b1] "=&v"(b1), [s1] "=&v"(s1), [n1] "=&v"(n1)
-                 : [l] "s"(lutk), [k] "s"(k));
+                 : [l] "s"(lut2), [k] "s"(k));
 }
 __device__ __forceinline__ void rot_mad24_x3(int32_t &x0, int32_t &y0, int32_t &z0, int32_t &x1, int32_t &y1, int32_t &z1,
-                                             int32_t &x2, int32_t &y2, int32_t &z2, int k, uint32_t lutk)
+                                             int32_t &x2, int32_t &y2, int32_t &z2, int k, uint32_t lut2)
 {
     int32_t a0, b0, s0, n0, a1, b1, s1, n1, a2, b2, s2, n2;
-    asm volatile("v_ashrrev_i32 %[n0], 31, %[z0]\n\tv_ashrrev_i32 %[n1], 31, %[z1]\n\tv_ashrrev_i32 %[n2], 31, %[z2]\n\t"
+    asm volatile("v_med3_i32 %[s0], %[z0], -1, 1\n\tv_med3_i32 %[s1], %[z1], -1, 1\n\tv_med3_i32 %[s2], %[z2], -1, 1\n\t"
                  "v_ashrrev_i32 %[a0], %[k], %[y0]\n\tv_ashrrev_i32 %[a1], %[k], %[y1]\n\tv_ashrrev_i32 %[a2], %[k], %[y2]\n\t"
-                 "v_or_b32 %[s0], 1, %[n0]\n\tv_or_b32 %[s1], 1, %[n1]\n\tv_or_b32 %[s2], 1, %[n2]\n\t"
                  "v_ashrrev_i32 %[b0], %[k], %[x0]\n\tv_ashrrev_i32 %[b1], %[k], %[x1]\n\tv_ashrrev_i32 %[b2], %[k], %[x2]\n\t"
                  "v_sub_u32 %[n0], 0, %[s0]\n\tv_sub_u32 %[n1], 0, %[s1]\n\tv_sub_u32 %[n2], 0, %[s2]\n\t"
                  "v_mad_i32_i24 %[y0], %[s0], %[b0], %[y0]\n\tv_mad_i32_i24 %[y1], %[s1], %[b1], %[y1]\n\tv_mad_i32_i24 %[y2], %[s2], %[b2], %[y2]\n\t"
@@ -161,7 +160,7 @@ __device__ __forceinline__ void rot_mad24_x3(int32_t &x0, int32_t &y0, int32_t &
                  : [x0] "+v"(x0), [y0] "+v"(y0), [z0] "+v"(z0), [x1] "+v"(x1), [y1] "+v"(y1), [z1] "+v"(z1), [x2] "+v"(x2), [y2] "+v"(y2), [z2] "+v"(z2),
                    [a0] "=&v"(a0), [b0] "=&v"(b0), [s0] "=&v"(s0), [n0] "=&v"(n0), [a1] "=&v"(a1), [b1] "=&v"(b1), [s1] "=&v"(s1), [n1] "=&v"(n1),
                    [a2] "=&v"(a2), [b2] "=&v"(b2), [s2] "=&v"(s2), [n2] "=&v"(n2)
-                 : [l] "s"(lutk), [k] "s"(k));
+                 : [l] "s"(lut2), [k] "s"(k));
 }
 // one rotation of all NCH chains of a lane (NCH = 2, 3, 5, 6, 9): groups of three, then what is left
 template <int NCH>
@@ -388,10 +387,14 @@ __global__ __launch_bounds__(kFoldBlock) void k_fold_direct(BhwWinCfg win, BhwFo
 #pragma unroll
             for (int c = 0; c < NCH; ++c) rot_narrow32(x[c], y[c], z[c], k, lutk);
         }
+        // from here on the angle is carried as 2 z + 1 (rot_mad24); it is not read after the last rotation
+        const uint32_t lutv2 = lutv << 1;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) z[c] = (int32_t)(((uint32_t)z[c] << 1) | 1u);
 #pragma unroll 1
         for (; k < n_iter; ++k) {
-            const uint32_t lutk = (uint32_t)__builtin_amdgcn_readlane((int)lutv, k);
-            rot_mad24_all<NCH>(x, y, z, k, lutk);
+            const uint32_t lut2 = (uint32_t)__builtin_amdgcn_readlane((int)lutv2, k);
+            rot_mad24_all<NCH>(x, y, z, k, lut2);
         }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) cs[c] = make_int2(x[c] >> out_shr, y[c] >> out_shr);

@@ -519,10 +519,11 @@ int bhwp_fold_form(const BhwCordicCfg &c, const BhwWinCfg &w, uint64_t total)
 
 uint32_t bhwp_fold_k24(const BhwCordicCfg &c)
 {
-    // |x|, |y| < 2^B, B = W + out_shr - 1: (x >> k) fits 24 signed bits from k = B - 23 on; the ROM word from the first lut[k] < 2^23 on
+    // |x|, |y| < 2^B, B = W + out_shr - 1: (x >> k) fits 24 signed bits from k = B - 23 on; twice the ROM word (the kernel carries the
+    // angle doubled: rot_mad24) from the first lut[k] < 2^22 on
     const int B = (int)(c.dat_width + c.out_shr) - 1;
     uint32_t k24 = B > 23 ? (uint32_t)(B - 23) : 1u;
-    while (k24 < c.n_iter && k24 < 32u && (uint32_t)c.lut[k24] >= (1u << 23)) ++k24;
+    while (k24 < c.n_iter && k24 < 32u && (uint32_t)c.lut[k24] >= (1u << 22)) ++k24;
     return k24;
 }
 
