@@ -257,7 +257,7 @@ int acquire_scratch(const bhw_exec *ex, int device, void *stream, uint64_t need,
     }
     t.slot = slot_of(device, stream);
     t.lock = std::unique_lock<std::mutex>(t.slot->mu);
-    if (t.slot->oversized && !open_verdicts && t.slot->bytes > need) {
+    if (t.slot->oversized && !open_verdicts && t.slot->bytes > need && !stream_is_capturing(stream)) {   // (a capture keeps the excess for a later call)
         t.slot->oversized = false;
         const int rs = shrink_slot_to(*t.slot, stream, need);
         if (rs) return rs;

@@ -248,6 +248,30 @@ def test_library_scratch_gives_the_excess_back_once_the_formats_are_settled(torc
         graph.replay()
         st2.synchronize()
         assert torch.equal(out2, first)
+    # an oversized slot met by a captured call: nothing is re-sized inside the capture (that would synchronise the stream), the graph
+    # uses the buffer as it is, and the next plain call gives the excess back
+    for k in (16 + 9, 48 + 9, 9, 6):
+        assert L.bhw_dbg_table_format_verdict(ctypes.byref(p), k, 3) == 0
+    st3 = torch.cuda.Stream()
+    with torch.cuda.stream(st3):
+        out3 = torch.zeros(n, dtype=torch.int32, device="cuda")
+        bhw.generate(p, 0, n, out=out3)                                                  # unprepared again: the slot of st3 takes the bound
+        st3.synchronize()
+        assert L.bhw_dbg_library_scratch_bytes(0, ctypes.c_void_p(st3.cuda_stream)) == bound
+        out3.zero_()
+        g3 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g3, stream=st3):
+            bhw.generate(p, 0, n, out=out3)
+        assert L.bhw_dbg_library_scratch_bytes(0, ctypes.c_void_p(st3.cuda_stream)) == bound
+        g3.replay()
+        st3.synchronize()
+        assert torch.equal(out3, first)
+        del g3                                                                           # (the graph's kernels hold the buffer's address)
+        out3.zero_()
+        bhw.generate(p, 0, n, out=out3)
+        st3.synchronize()
+        assert L.bhw_dbg_library_scratch_bytes(0, ctypes.c_void_p(st3.cuda_stream)) == tight
+        assert torch.equal(out3, first)
 
 
 def _dbg():
